@@ -1,0 +1,168 @@
+/*
+ * mcd.h -- C-ABI of the MI355X-native log-likelihood hot path of mcmc_dynamics.
+ *
+ * The reference (skamann/mcmc-dynamics, pure Python) has no FFI of its own; its boundary for this
+ * path is the bound method `Runner.lnprob` handed to emcee (analysis/runner.py:288-306, :403).
+ * The entry points below are what a ctypes/cffi binding inside `Runner` binds to replace the
+ * NumPy/astropy body of that method:
+ *
+ *   mcd_catalog_create   replaces the per-instance column extraction of `Runner.__init__`
+ *                        (analysis/runner.py:75-81, :96-106) and the walker-independent part of
+ *                        `calc_xy_offset` + `arctan2` (utils/coordinates/calc_xy_offset.py:9-33,
+ *                        analysis/constant.py:106-107): star columns are copied to HBM ONCE.
+ *   mcd_loglike_batch    replaces `ConstantFit.lnlike` / `ConstantFitGB.lnlike` /
+ *                        `Runner._calculate_lnlike` (analysis/constant.py:113-154, :293-364;
+ *                        analysis/runner.py:240-286) for W walkers per call.
+ *   mcd_membership       replaces `ConstantFitGB.calculate_membership_probabilities`
+ *                        (analysis/constant.py:366-374).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all arrays are float64 unless stated; canonical units of the
+ *     reference: deg (ra, dec, centres), km/s (velocities), dimensionless (pmember, density, f_back).
+ *   - the caller owns every host buffer; the library copies inputs during the call and never keeps
+ *     a host pointer.  `out` buffers are caller-allocated.
+ *   - every function returns 0 on success or a negative mcd_status; `mcd_last_error()` returns a
+ *     thread-local message.  No C++ exception crosses this boundary.
+ *   - results are deterministic: fixed chunking and a fixed reduction tree (no float atomics).
+ */
+#ifndef MCD_H
+#define MCD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCD_ABI_VERSION 1
+#define MCD_UNIQUE_ID_BYTES 128
+
+typedef struct mcd_ctx mcd_ctx;          /* devices + streams (+ RCCL communicator when > 1 rank) */
+typedef struct mcd_catalog mcd_catalog;  /* HBM-resident star records of one Runner instance     */
+
+typedef enum {
+    MCD_OK = 0,
+    MCD_ERR_INVALID = -1,   /* bad argument (null pointer, size, enum, K mismatch)  */
+    MCD_ERR_HIP = -2,       /* a HIP runtime call failed (message has the call)     */
+    MCD_ERR_RCCL = -3,      /* an RCCL call failed                                  */
+    MCD_ERR_NO_DEVICE = -4, /* no usable gfx950 device                              */
+    MCD_ERR_NONFINITE = -5  /* reserved: non-finite input detected at upload        */
+} mcd_status;
+
+/* which per-star likelihood the catalogue is evaluated with */
+typedef enum {
+    MCD_MODEL_CONST = 0,          /* ConstantFit, no background  (runner.py:264-271)                 */
+    MCD_MODEL_CONST_BGFIXED = 1,  /* ConstantFit + fixed per-star background lnL and pmember
+                                     (runner.py:272-286; background/gaussian.py:23-28)              */
+    MCD_MODEL_CONST_BGGAUSS = 2,  /* ConstantFitGB: per-walker (v_back, sigma_back, f_back) and the
+                                     `density` prior (constant.py:293-364)                          */
+    MCD_MODEL_PROFILE = 3,        /* ModelFit: Lynden-Bell rotation curve + Plummer dispersion
+                                     (analysis/model.py:93-180); needs per-star radius              */
+    MCD_MODEL_PROFILE_BGGAUSS = 4 /* ModelFitGB (analysis/model.py:391-456)                          */
+} mcd_model;
+
+typedef enum {
+    MCD_CENTRE_FIXED = 0,  /* (ra_center, dec_center) fixed: sin/cos(theta_i) precomputed at upload */
+    MCD_CENTRE_FREE = 1    /* centre is a walker parameter: geometry recomputed per term            */
+} mcd_centre;
+
+typedef enum {
+    MCD_F64 = 0,        /* float64 terms, float64 accumulation (parity mode)      */
+    MCD_F32 = 1,        /* float32 terms, float32 accumulation                     */
+    MCD_F32_ACC64 = 2   /* float32 terms, float64 accumulation                     */
+} mcd_precision;
+
+/* Catalogue description.  Pointers not needed by `model` may be NULL. */
+typedef struct {
+    int64_t n_stars;
+    const double* ra;         /* deg  */
+    const double* dec;        /* deg  */
+    const double* v;          /* km/s */
+    const double* verr;       /* km/s */
+    const double* lnlike_bg;  /* MCD_MODEL_CONST_BGFIXED: background(v, verr) per star            */
+    const double* pmember;    /* MCD_MODEL_CONST_BGFIXED: prior membership probability            */
+    const double* density;    /* *_BGGAUSS: normalised stellar surface density                     */
+    int32_t model;            /* mcd_model     */
+    int32_t centre;           /* mcd_centre    */
+    int32_t precision;        /* mcd_precision */
+    int32_t reserved;
+    double ra_center;         /* deg; used when centre == MCD_CENTRE_FIXED                         */
+    double dec_center;        /* deg                                                               */
+    int64_t n_bins;           /* 0 or 1: one parameter set for all stars.  B > 1: radial bins
+                                 (utils/files/data_reader.py:71-140); stars must be sorted by bin   */
+    const int64_t* bin_offsets; /* n_bins + 1 offsets into the star arrays when n_bins > 1        */
+} mcd_catalog_desc;
+
+/* ---- context ------------------------------------------------------------------------------ */
+
+/* Single process driving n_dev devices (dev_ids == NULL: devices 0..n_dev-1).  With n_dev > 1 the
+ * catalogue is sharded over the devices and per-walker partial sums are combined with one
+ * ncclAllReduce(sum, f64, count = outputs) per batched call (communicator from ncclCommInitAll). */
+int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out);
+
+/* One process per GPU (torchrun-style).  Rank 0 calls mcd_get_unique_id and distributes the
+ * MCD_UNIQUE_ID_BYTES blob out of band; every rank then calls mcd_ctx_create_rank.  Each rank
+ * uploads ITS shard of the stars; mcd_loglike_batch all-reduces so every rank gets the total.
+ * n_ranks == 1 needs no id (unique_id may be NULL) and never touches RCCL. */
+int mcd_get_unique_id(void* out_id);
+int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id, mcd_ctx** out);
+
+int mcd_ctx_destroy(mcd_ctx* ctx);
+int mcd_ctx_n_devices(const mcd_ctx* ctx);
+
+/* ---- catalogue ---------------------------------------------------------------------------- */
+
+int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* desc, mcd_catalog** out);
+int mcd_catalog_destroy(mcd_catalog* cat);
+
+/* Number of columns K of the resolved parameter table expected by mcd_loglike_batch:
+ *   CONST    : v_sys, sigma_max, v_maxx, v_maxy [, ra_center, dec_center]
+ *   *_BGGAUSS: ... + v_back, sigma_back, f_back
+ *   PROFILE  : v_sys, sigma_max, a, v_maxx, v_maxy, r_peak [, ra_center, dec_center] (a, r_peak in arcsec)
+ * (order of config/constant.json:6-11, constant_with_background.json:6-14, model.json:6-13 with the
+ * centre moved behind the model parameters). */
+int mcd_catalog_param_count(const mcd_catalog* cat);
+int64_t mcd_catalog_n_stars(const mcd_catalog* cat);      /* stars held by THIS process */
+int64_t mcd_catalog_n_outputs(const mcd_catalog* cat, int64_t n_walkers); /* W * max(1, n_bins) */
+
+/* ---- evaluation --------------------------------------------------------------------------- */
+
+/* Log-likelihood of W walkers.  params: row-major [max(1,n_bins)][W][K]; out: [max(1,n_bins)][W].
+ * Synchronous: H2D of params, kernels, reduction, (all-reduce), D2H of out. */
+int mcd_loglike_batch(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, double* out);
+
+/* Device-resident pipeline used by throughput measurements and by callers that keep walkers on the
+ * GPU: stage params once, enqueue any number of evaluations, fetch the last result. */
+int mcd_params_upload(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params);
+int mcd_loglike_enqueue(mcd_catalog* cat);                 /* asynchronous on the catalogue's stream(s) */
+int mcd_loglike_fetch(mcd_catalog* cat, double* out);      /* waits, copies [max(1,n_bins)][W] doubles    */
+int mcd_sync(mcd_catalog* cat);
+
+/* Posterior membership probability per star for ONE parameter row (BGGAUSS models):
+ * m e^{lc} / (m e^{lc} + (1 - m) e^{lb}); out has n_stars doubles (this process' shard). */
+int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* out);
+
+/* ---- introspection for the measurement harness ------------------------------------------- */
+
+const char* mcd_last_error(void);
+int mcd_abi_version(void);
+/* HIP-event time of the most recent mcd_loglike_batch / enqueue+sync: main kernel only, and the
+ * whole device-side sequence (prep + main + reduce), milliseconds, device 0 of this process. */
+double mcd_last_kernel_ms(const mcd_catalog* cat);
+double mcd_last_device_ms(const mcd_catalog* cat);
+/* Tuning / measurement switches, per catalogue.  Keys:
+ *   "timing"        1: record HIP events around every enqueue (default 0)
+ *   "fast_path"     0: always use the plain per-term log/divide kernels (default 1: the fraction-tree /
+ *                      log-product kernel is used whenever the per-call range guard allows it)
+ *   "target_waves"  number of waves the chunking aims for per device (default 8192)
+ * Returns MCD_ERR_INVALID for an unknown key. */
+int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value);
+/* Launch geometry of the main kernel for the last call: workgroups, walker tile (walkers that
+ * reuse one star record load), chunks per parameter set, bytes per star record. */
+int mcd_last_launch_info(const mcd_catalog* cat, int64_t* n_workgroups, int32_t* walker_tile,
+                         int64_t* n_chunks, int32_t* record_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCD_H */

@@ -1,0 +1,307 @@
+"""ctypes binding of the C-ABI in ``include/mcd.h`` (``libmcd_hip.so``, built by ``csrc/Makefile``).
+
+This is the only route from the Python host code to the GPU: there is no CPU fallback.  If the
+library is missing or no gfx950 device is usable, the functions here raise ``NativeError``.
+"""
+import atexit
+import ctypes
+import os
+import weakref
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcd_hip.so")
+
+MODEL_CONST, MODEL_CONST_BGFIXED, MODEL_CONST_BGGAUSS = 0, 1, 2
+CENTRE_FIXED, CENTRE_FREE = 0, 1
+F64, F32, F32_ACC64 = 0, 1, 2
+PRECISIONS = {"f64": F64, "f32": F32, "f32acc64": F32_ACC64}
+UNIQUE_ID_BYTES = 128
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+
+# every symbol include/mcd.h declares: (restype, argtypes)
+SYMBOLS = {
+    "mcd_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p)]),
+    "mcd_get_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_ctx_create_rank": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.POINTER(ctypes.c_void_p)]),
+    "mcd_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_ctx_n_devices": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_catalog_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "mcd_catalog_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_catalog_param_count": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_catalog_n_stars": (ctypes.c_int64, [ctypes.c_void_p]),
+    "mcd_catalog_n_outputs": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
+    "mcd_loglike_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p]),
+    "mcd_params_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, _c_double_p]),
+    "mcd_loglike_enqueue": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_loglike_fetch": (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
+    "mcd_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_membership": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_double_p, _c_double_p]),
+    "mcd_last_error": (ctypes.c_char_p, []),
+    "mcd_abi_version": (ctypes.c_int, []),
+    "mcd_last_kernel_ms": (ctypes.c_double, [ctypes.c_void_p]),
+    "mcd_last_device_ms": (ctypes.c_double, [ctypes.c_void_p]),
+    "mcd_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
+    "mcd_last_launch_info": (ctypes.c_int, [ctypes.c_void_p, _c_int64_p, ctypes.POINTER(ctypes.c_int32), _c_int64_p,
+                                            ctypes.POINTER(ctypes.c_int32)]),
+}
+
+
+class NativeError(RuntimeError):
+    """Raised when the HIP library is missing, fails to load, or a call returns an error status."""
+
+
+class CatalogDesc(ctypes.Structure):
+    """Mirror of ``mcd_catalog_desc``."""
+    _fields_ = [
+        ("n_stars", ctypes.c_int64),
+        ("ra", _c_double_p), ("dec", _c_double_p), ("v", _c_double_p), ("verr", _c_double_p),
+        ("lnlike_bg", _c_double_p), ("pmember", _c_double_p), ("density", _c_double_p),
+        ("model", ctypes.c_int32), ("centre", ctypes.c_int32), ("precision", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("ra_center", ctypes.c_double), ("dec_center", ctypes.c_double),
+        ("n_bins", ctypes.c_int64), ("bin_offsets", _c_int64_p),
+    ]
+
+
+_lib = None
+_live_catalogs = weakref.WeakSet()
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _shutdown():
+    """Release device objects in dependency order (catalogues, then contexts) while the interpreter
+    and the HIP runtime are both still fully alive; nothing is left for __del__ at teardown."""
+    for cat in list(_live_catalogs):
+        try:
+            cat.close()
+        except Exception:
+            pass
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+
+
+def load_library(path=None):
+    """Load ``libmcd_hip.so`` and declare every entry point.  Raises NativeError if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise NativeError(
+            "HIP library not found at {0}: build it with `make -C mcmc_dynamics_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback.".format(p))
+    try:
+        lib = ctypes.CDLL(p)
+    except OSError as exc:
+        raise NativeError("could not load {0}: {1}".format(p, exc))
+    for name, (restype, argtypes) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise NativeError("{0} does not export {1}".format(p, name))
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        msg = lib.mcd_last_error()
+        raise NativeError("{0} failed (status {1}): {2}".format(what, rc, msg.decode() if msg else ""))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_c_double_p) if a is not None else None
+
+
+class Context(object):
+    """HIP devices + streams (+ RCCL communicator).  One per process."""
+
+    def __init__(self, n_devices=1, device_ids=None, rank=None, n_ranks=None, unique_id=None, device=None):
+        self.lib = load_library()
+        handle = ctypes.c_void_p()
+        if rank is not None:
+            uid = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES) if unique_id is not None else None
+            rc = self.lib.mcd_ctx_create_rank(int(device or 0), int(rank), int(n_ranks), uid, ctypes.byref(handle))
+            _check(self.lib, rc, "mcd_ctx_create_rank")
+            self.rank, self.n_ranks = int(rank), int(n_ranks)
+        else:
+            ids = None
+            if device_ids is not None:
+                ids = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+                n_devices = len(device_ids)
+            rc = self.lib.mcd_ctx_create(int(n_devices), ids, ctypes.byref(handle))
+            _check(self.lib, rc, "mcd_ctx_create")
+            self.rank, self.n_ranks = 0, 1
+        self.handle = handle
+        _live_contexts.add(self)
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+        _check(lib, lib.mcd_get_unique_id(buf), "mcd_get_unique_id")
+        return buf.raw
+
+    @property
+    def n_devices(self):
+        return self.lib.mcd_ctx_n_devices(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mcd_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide single-GPU context (device 0), created on first use."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(n_devices=1)
+    return _default_ctx
+
+
+class Catalog(object):
+    """Star records resident in HBM; evaluates the log-likelihood of batches of walkers."""
+
+    def __init__(self, ctx, ra, dec, v, verr, model=MODEL_CONST, centre=None, lnlike_bg=None, pmember=None,
+                 density=None, bin_offsets=None, precision="f64"):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        cols = [_f64(ra), _f64(dec), _f64(v), _f64(verr)]
+        n = cols[0].size
+        if any(c.size != n for c in cols):
+            raise ValueError("ra, dec, v, verr must have the same length")
+        extras = [None if a is None else _f64(a) for a in (lnlike_bg, pmember, density)]
+        if any(a is not None and a.size != n for a in extras):
+            raise ValueError("background columns must have the same length as the catalogue")
+        d = CatalogDesc()
+        d.n_stars = n
+        d.ra, d.dec, d.v, d.verr = (_ptr(c) for c in cols)
+        d.lnlike_bg, d.pmember, d.density = (_ptr(a) for a in extras)
+        d.model = int(model)
+        d.precision = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        if centre is None:
+            d.centre = CENTRE_FREE
+        else:
+            d.centre = CENTRE_FIXED
+            d.ra_center, d.dec_center = float(centre[0]), float(centre[1])
+        offs = None
+        if bin_offsets is not None and len(bin_offsets) > 2:
+            offs = np.ascontiguousarray(bin_offsets, dtype=np.int64)
+            d.n_bins = offs.size - 1
+            d.bin_offsets = offs.ctypes.data_as(_c_int64_p)
+        else:
+            d.n_bins = 0
+        handle = ctypes.c_void_p()
+        rc = self.lib.mcd_catalog_create(ctx.handle, ctypes.byref(d), ctypes.byref(handle))
+        _check(self.lib, rc, "mcd_catalog_create")
+        self.handle = handle
+        self.n_stars = n
+        self.n_sets = max(1, int(d.n_bins))
+        self.k = self.lib.mcd_catalog_param_count(handle)
+        self._walkers = 0
+        _live_catalogs.add(self)
+
+    def _params(self, params):
+        p = _f64(params)
+        if p.ndim == 1:
+            p = p[None, :]
+        if self.n_sets > 1:
+            if p.ndim != 3 or p.shape[0] != self.n_sets:
+                raise ValueError("binned catalogue expects params of shape (n_bins, W, K)")
+            w = p.shape[1]
+        else:
+            if p.ndim == 3 and p.shape[0] == 1:
+                p = p[0]
+            if p.ndim != 2:
+                raise ValueError("params must have shape (W, K)")
+            w = p.shape[0]
+        if p.shape[-1] != self.k:
+            raise ValueError("params have {0} columns, catalogue expects {1}".format(p.shape[-1], self.k))
+        return np.ascontiguousarray(p), w
+
+    def loglike(self, params):
+        """(W, K) -> (W,)   [binned: (B, W, K) -> (B, W)]   synchronous."""
+        p, w = self._params(params)
+        out = np.empty((self.n_sets, w) if self.n_sets > 1 else (w,), dtype=np.float64)
+        rc = self.lib.mcd_loglike_batch(self.handle, w, self.k, _ptr(p), _ptr(out))
+        _check(self.lib, rc, "mcd_loglike_batch")
+        self._walkers = w
+        return out
+
+    def upload_params(self, params):
+        p, w = self._params(params)
+        _check(self.lib, self.lib.mcd_params_upload(self.handle, w, self.k, _ptr(p)), "mcd_params_upload")
+        self._walkers = w
+
+    def enqueue(self):
+        _check(self.lib, self.lib.mcd_loglike_enqueue(self.handle), "mcd_loglike_enqueue")
+
+    def sync(self):
+        _check(self.lib, self.lib.mcd_sync(self.handle), "mcd_sync")
+
+    def fetch(self):
+        w = self._walkers
+        out = np.empty((self.n_sets, w) if self.n_sets > 1 else (w,), dtype=np.float64)
+        _check(self.lib, self.lib.mcd_loglike_fetch(self.handle, _ptr(out)), "mcd_loglike_fetch")
+        return out
+
+    def membership(self, params_row):
+        p = _f64(params_row).reshape(-1)
+        out = np.empty(self.n_stars, dtype=np.float64)
+        _check(self.lib, self.lib.mcd_membership(self.handle, p.size, _ptr(p), _ptr(out)), "mcd_membership")
+        return out
+
+    def set_option(self, key, value):
+        _check(self.lib, self.lib.mcd_set_option(self.handle, key.encode(), int(value)), "mcd_set_option")
+
+    @property
+    def last_kernel_ms(self):
+        return self.lib.mcd_last_kernel_ms(self.handle)
+
+    @property
+    def last_device_ms(self):
+        return self.lib.mcd_last_device_ms(self.handle)
+
+    def launch_info(self):
+        wg, ch = ctypes.c_int64(), ctypes.c_int64()
+        tile, rb = ctypes.c_int32(), ctypes.c_int32()
+        _check(self.lib, self.lib.mcd_last_launch_info(self.handle, ctypes.byref(wg), ctypes.byref(tile),
+                                                       ctypes.byref(ch), ctypes.byref(rb)), "mcd_last_launch_info")
+        return {"workgroups": wg.value, "walker_tile": tile.value, "chunks": ch.value, "record_bytes": rb.value}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mcd_catalog_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

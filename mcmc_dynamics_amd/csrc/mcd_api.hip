@@ -1,0 +1,687 @@
+// mcd_api.hip -- C-ABI of the MI355X log-likelihood library (see include/mcd.h).
+//
+// Host-side responsibilities: device/stream/communicator set-up, one-off upload and packing of the
+// star catalogue into HBM, star sharding across devices, chunk tables, per-call launch sequence
+//   params H2D -> walker prep -> main kernel -> fixed-order reduce -> [RCCL all-reduce] -> D2H,
+// and HIP-event timing for the measurement harness.  No C++ exception leaves this file.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl.so is dlopen'ed on first multi-GPU use
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mcd.h"
+#include "mcd_internal.h"
+#include "mcd_math.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define MCD_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(MCD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+// RCCL entry points, resolved lazily so that single-GPU processes never load or initialise RCCL.
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.handle) return MCD_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(MCD_ERR_RCCL, std::string("cannot load librccl.so: ") + dlerror());
+#define MCD_SYM(field, name)                                                                            \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));                            \
+    if (!g_rccl.field) return fail(MCD_ERR_RCCL, std::string("librccl.so lacks ") + name);
+    MCD_SYM(GetUniqueId, "ncclGetUniqueId")
+    MCD_SYM(CommInitRank, "ncclCommInitRank")
+    MCD_SYM(CommInitAll, "ncclCommInitAll")
+    MCD_SYM(CommDestroy, "ncclCommDestroy")
+    MCD_SYM(AllReduce, "ncclAllReduce")
+    MCD_SYM(GroupStart, "ncclGroupStart")
+    MCD_SYM(GroupEnd, "ncclGroupEnd")
+    MCD_SYM(GetErrorString, "ncclGetErrorString")
+#undef MCD_SYM
+    g_rccl.handle = h;
+    return MCD_OK;
+}
+
+#define MCD_NCCL(call)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r_ = (call);                                                                       \
+        if (r_ != ncclSuccess)                                                                          \
+            return fail(MCD_ERR_RCCL, std::string(#call) + ": " + g_rccl.GetErrorString(r_));           \
+    } while (0)
+
+struct DeviceSlot {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+};
+
+// per-(shard, walker-count) work buffers
+struct WorkSet {
+    int64_t n_walkers = 0;
+    int64_t n_chunks = 0;
+    int64_t max_chunks_per_pset = 0;
+    mcd::Chunk* d_chunks = nullptr;
+    int64_t* d_offsets = nullptr;      // [n_psets + 1] chunk offsets
+    double* d_params = nullptr;        // [n_psets][W][K]
+    void* d_wpar = nullptr;            // [n_psets][W][KD]
+    double* d_partials = nullptr;      // [W][n_chunks]
+    double* d_out = nullptr;           // [n_psets][W]
+    double* h_params = nullptr;        // pinned
+    double* h_out = nullptr;           // pinned
+    bool fast = false;
+    bool staged = false;
+};
+
+struct Shard {
+    int slot = 0;                      // index into ctx->slots
+    int64_t star_begin = 0;            // global index of the first star held here
+    int64_t n = 0;
+    void* records = nullptr;
+    std::map<int64_t, WorkSet> work;   // keyed by walker count
+    hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
+};
+
+}  // namespace
+
+struct mcd_ctx {
+    std::vector<DeviceSlot> slots;
+    int rank = 0;
+    int n_ranks = 1;
+    bool multi_process = false;
+};
+
+struct mcd_catalog {
+    mcd_ctx* ctx = nullptr;
+    int model = 0;
+    bool free_centre = false;
+    int precision = 0;
+    int k = 4;
+    int64_t n_stars = 0;               // stars held by this process
+    int64_t n_psets = 1;
+    std::vector<int64_t> bin_offsets;  // [n_psets + 1], indices into this process' stars
+    std::vector<Shard> shards;
+    // range statistics for the fast-path guard
+    double e2_min = 0, e2_max = 0, v_abs_max = 0;
+    double rho_min = 0, rho_max = 0;
+    bool stats_finite = true;
+    bool extras_ok = true;             // background columns inside the fast-path ranges
+    // options
+    bool timing = false;
+    bool allow_fast = true;
+    int64_t target_waves = 8192;
+    // state of the last evaluation
+    int64_t cur_walkers = 0;
+    double last_kernel_ms = -1.0, last_device_ms = -1.0;
+    bool timing_pending = false;
+    int64_t last_grid = 0, last_chunks = 0;
+};
+
+namespace {
+
+int param_count(int model, bool free_centre) {
+    int k = 4 + (free_centre ? 2 : 0);
+    if (model == MCD_MODEL_CONST_BGGAUSS) k += 3;
+    return k;
+}
+
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+void free_workset(WorkSet& w) {
+    if (w.d_chunks) (void)hipFree(w.d_chunks);
+    if (w.d_offsets) (void)hipFree(w.d_offsets);
+    if (w.d_params) (void)hipFree(w.d_params);
+    if (w.d_wpar) (void)hipFree(w.d_wpar);
+    if (w.d_partials) (void)hipFree(w.d_partials);
+    if (w.d_out) (void)hipFree(w.d_out);
+    if (w.h_params) (void)hipHostFree(w.h_params);
+    if (w.h_out) (void)hipHostFree(w.h_out);
+    w = WorkSet();
+}
+
+// Chunk table of one shard for a given walker count: every parameter set (bin) is cut into runs of
+// `len` stars (a multiple of 8 so that only the last chunk of a set has a tail).
+int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out) {
+    auto it = sh.work.find(n_walkers);
+    if (it != sh.work.end()) { *out = &it->second; return MCD_OK; }
+    if (sh.work.size() >= 8) {                       // bound the cache (emcee uses W and W/2)
+        for (auto& kv : sh.work) free_workset(kv.second);
+        sh.work.clear();
+    }
+    const DeviceSlot& slot = cat->ctx->slots[sh.slot];
+    MCD_HIP(hipSetDevice(slot.device));
+
+    const int64_t n_wtiles = (n_walkers + 63) / 64;
+    int64_t len = (sh.n * n_wtiles + cat->target_waves - 1) / std::max<int64_t>(1, cat->target_waves);
+    len = std::max<int64_t>(64, round_up(len, 8));
+
+    std::vector<mcd::Chunk> chunks;
+    std::vector<int64_t> offs(cat->n_psets + 1, 0);
+    int64_t max_per = 0;
+    for (int64_t p = 0; p < cat->n_psets; ++p) {
+        offs[p] = (int64_t)chunks.size();
+        const int64_t b0 = std::max(cat->bin_offsets[p], sh.star_begin);
+        const int64_t b1 = std::min(cat->bin_offsets[p + 1], sh.star_begin + sh.n);
+        for (int64_t s = b0; s < b1; s += len) {
+            mcd::Chunk c;
+            c.begin = s - sh.star_begin;
+            c.count = (int32_t)std::min(len, b1 - s);
+            c.pset = (int32_t)p;
+            chunks.push_back(c);
+        }
+        max_per = std::max<int64_t>(max_per, (int64_t)chunks.size() - offs[p]);
+    }
+    offs[cat->n_psets] = (int64_t)chunks.size();
+
+    WorkSet w;
+    w.n_walkers = n_walkers;
+    w.n_chunks = (int64_t)chunks.size();
+    w.max_chunks_per_pset = max_per;
+    const int64_t n_out = cat->n_psets * n_walkers;
+    const size_t term_bytes = cat->precision == MCD_F64 ? 8 : 4;
+    MCD_HIP(hipMalloc(&w.d_chunks, std::max<size_t>(1, chunks.size()) * sizeof(mcd::Chunk)));
+    MCD_HIP(hipMalloc(&w.d_offsets, offs.size() * sizeof(int64_t)));
+    MCD_HIP(hipMalloc(&w.d_params, (size_t)n_out * cat->k * sizeof(double)));
+    MCD_HIP(hipMalloc(&w.d_wpar, (size_t)n_out * mcd::KD * term_bytes));
+    MCD_HIP(hipMalloc(&w.d_partials, std::max<size_t>(1, (size_t)n_walkers * w.n_chunks) * sizeof(double)));
+    MCD_HIP(hipMalloc(&w.d_out, (size_t)n_out * sizeof(double)));
+    MCD_HIP(hipHostMalloc(&w.h_params, (size_t)n_out * cat->k * sizeof(double), hipHostMallocDefault));
+    MCD_HIP(hipHostMalloc(&w.h_out, (size_t)n_out * sizeof(double), hipHostMallocDefault));
+    if (!chunks.empty())
+        MCD_HIP(hipMemcpy(w.d_chunks, chunks.data(), chunks.size() * sizeof(mcd::Chunk), hipMemcpyHostToDevice));
+    MCD_HIP(hipMemcpy(w.d_offsets, offs.data(), offs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    auto ins = sh.work.emplace(n_walkers, w);
+    *out = &ins.first->second;
+    return MCD_OK;
+}
+
+// Fast paths (f64 only) are valid while their intermediate products stay far from over/underflow.
+//   CONST   (fraction tree over 8 stars + log product): 2^-60 <= verr^2 + sigma^2 <= 2^60, |v - v_los| < 2^58
+//   BGFIXED / BGGAUSS (rsqrt + one exp + log product):  2^-200 <= norm <= 2^200, finite columns,
+//            lnlike_bg > -1e5, 0 <= pmember <= 1;  density >= 0, f_back >= 0, 2^-100 <= density + f_back <= 2^100
+// Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
+// expressions term by term.
+bool fast_guard(const mcd_catalog* cat, const double* params, int64_t n_rows) {
+    if (!cat->allow_fast || cat->precision != MCD_F64) return false;
+    if (!cat->stats_finite) return false;
+    const int k = cat->k;
+    double s2_min = std::numeric_limits<double>::infinity(), s2_max = 0.0, amp = 0.0;
+    double sb2_min = s2_min, sb2_max = 0.0, f_min = s2_min, f_max = 0.0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const double* p = params + i * k;
+        const double s2 = p[1] * p[1];
+        double a = std::fabs(p[0]) + std::fabs(p[2]) + std::fabs(p[3]);
+        if (cat->model == MCD_MODEL_CONST_BGGAUSS) {
+            const double sb2 = p[k - 2] * p[k - 2], f = p[k - 1];
+            a = std::max(a, std::fabs(p[k - 3]));
+            if (!(std::isfinite(sb2) && std::isfinite(f))) return false;
+            sb2_min = std::min(sb2_min, sb2); sb2_max = std::max(sb2_max, sb2);
+            f_min = std::min(f_min, f); f_max = std::max(f_max, f);
+        }
+        if (cat->free_centre && !(std::isfinite(p[4]) && std::isfinite(p[5]))) return false;
+        if (!(std::isfinite(s2) && std::isfinite(a))) return false;
+        s2_min = std::min(s2_min, s2);
+        s2_max = std::max(s2_max, s2);
+        amp = std::max(amp, a);
+    }
+    if (n_rows == 0) return false;
+    if (!(cat->v_abs_max + amp <= std::ldexp(1.0, 58))) return false;
+    if (cat->model == MCD_MODEL_CONST)
+        return (cat->e2_min + s2_min >= std::ldexp(1.0, -60)) && (cat->e2_max + s2_max <= std::ldexp(1.0, 60));
+    const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
+    if (!((cat->e2_min + s2_min >= lo) && (cat->e2_max + s2_max <= hi))) return false;
+    if (cat->model == MCD_MODEL_CONST_BGFIXED) return cat->extras_ok;
+    if (!((cat->e2_min + sb2_min >= lo) && (cat->e2_max + sb2_max <= hi))) return false;
+    return cat->extras_ok && f_min >= 0.0 && (cat->rho_min + f_min >= std::ldexp(1.0, -100)) &&
+           (cat->rho_max + f_max <= std::ldexp(1.0, 100));
+}
+
+int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params) {
+    if (!cat || !params) return fail(MCD_ERR_INVALID, "null catalogue or params");
+    if (n_walkers <= 0) return fail(MCD_ERR_INVALID, "n_walkers must be positive");
+    if (k != cat->k) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "parameter table has %d columns, catalogue expects %d", (int)k, cat->k);
+        return fail(MCD_ERR_INVALID, buf);
+    }
+    const int64_t n_rows = cat->n_psets * n_walkers;
+    const bool fast = fast_guard(cat, params, n_rows);
+    for (Shard& sh : cat->shards) {
+        WorkSet* w = nullptr;
+        int rc = build_workset(cat, sh, n_walkers, &w);
+        if (rc != MCD_OK) return rc;
+        const DeviceSlot& slot = cat->ctx->slots[sh.slot];
+        MCD_HIP(hipSetDevice(slot.device));
+        // the pinned staging buffer may still be in flight from the previous call
+        MCD_HIP(hipStreamSynchronize(slot.stream));
+        std::memcpy(w->h_params, params, (size_t)n_rows * k * sizeof(double));
+        MCD_HIP(hipMemcpyAsync(w->d_params, w->h_params, (size_t)n_rows * k * sizeof(double), hipMemcpyHostToDevice,
+                               slot.stream));
+        MCD_HIP(mcd::launch_prepare_walkers(slot.stream, w->d_params, n_rows, k, cat->model, cat->free_centre,
+                                            cat->precision, w->d_wpar));
+        w->fast = fast;
+        w->staged = true;
+    }
+    cat->cur_walkers = n_walkers;
+    return MCD_OK;
+}
+
+int enqueue(mcd_catalog* cat) {
+    if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
+    if (cat->cur_walkers <= 0) return fail(MCD_ERR_INVALID, "no parameters staged (call mcd_params_upload first)");
+    const int64_t W = cat->cur_walkers;
+    const int64_t n_out = cat->n_psets * W;
+    mcd_ctx* ctx = cat->ctx;
+    for (Shard& sh : cat->shards) {
+        WorkSet& w = sh.work.at(W);
+        if (!w.staged) return fail(MCD_ERR_INVALID, "no parameters staged for this walker count");
+        const DeviceSlot& slot = ctx->slots[sh.slot];
+        MCD_HIP(hipSetDevice(slot.device));
+        mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast};
+        if (cat->timing) MCD_HIP(hipEventRecord(sh.ev_begin, slot.stream));
+        if (cat->timing) MCD_HIP(hipEventRecord(sh.ev_k0, slot.stream));
+        MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, W));
+        if (cat->timing) MCD_HIP(hipEventRecord(sh.ev_k1, slot.stream));
+        MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, w.n_chunks,
+                                   w.max_chunks_per_pset, W, w.d_out));
+    }
+    // sum the per-device / per-rank partial log-likelihoods: one all-reduce of n_out doubles
+    const bool collective = ctx->n_ranks > 1 || ctx->slots.size() > 1;
+    if (collective) {
+        if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
+        for (Shard& sh : cat->shards) {
+            WorkSet& w = sh.work.at(W);
+            const DeviceSlot& slot = ctx->slots[sh.slot];
+            MCD_HIP(hipSetDevice(slot.device));
+            MCD_NCCL(g_rccl.AllReduce(w.d_out, w.d_out, (size_t)n_out, ncclDouble, ncclSum, slot.comm, slot.stream));
+        }
+        if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
+    }
+    if (cat->timing) {
+        for (Shard& sh : cat->shards) {
+            const DeviceSlot& slot = ctx->slots[sh.slot];
+            MCD_HIP(hipSetDevice(slot.device));
+            MCD_HIP(hipEventRecord(sh.ev_end, slot.stream));
+        }
+        cat->timing_pending = true;
+    }
+    {
+        WorkSet& w0 = cat->shards[0].work.at(W);
+        const int64_t n_wtiles = (W + 63) / 64;
+        cat->last_chunks = w0.n_chunks;
+        cat->last_grid = (w0.n_chunks * n_wtiles + 3) / 4;
+    }
+    return MCD_OK;
+}
+
+int sync_all(mcd_catalog* cat) {
+    if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
+    for (Shard& sh : cat->shards) {
+        const DeviceSlot& slot = cat->ctx->slots[sh.slot];
+        MCD_HIP(hipSetDevice(slot.device));
+        MCD_HIP(hipStreamSynchronize(slot.stream));
+    }
+    if (cat->timing && cat->timing_pending) {
+        Shard& sh = cat->shards[0];
+        float k_ms = 0.f, d_ms = 0.f;
+        MCD_HIP(hipEventElapsedTime(&k_ms, sh.ev_k0, sh.ev_k1));
+        MCD_HIP(hipEventElapsedTime(&d_ms, sh.ev_begin, sh.ev_end));
+        cat->last_kernel_ms = k_ms;
+        cat->last_device_ms = d_ms;
+        cat->timing_pending = false;
+    }
+    return MCD_OK;
+}
+
+int fetch(mcd_catalog* cat, double* out) {
+    if (!cat || !out) return fail(MCD_ERR_INVALID, "null catalogue or output");
+    if (cat->cur_walkers <= 0) return fail(MCD_ERR_INVALID, "nothing evaluated yet");
+    const int64_t W = cat->cur_walkers;
+    const int64_t n_out = cat->n_psets * W;
+    Shard& sh = cat->shards[0];
+    WorkSet& w = sh.work.at(W);
+    const DeviceSlot& slot = cat->ctx->slots[sh.slot];
+    MCD_HIP(hipSetDevice(slot.device));
+    MCD_HIP(hipMemcpyAsync(w.h_out, w.d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
+    int rc = sync_all(cat);
+    if (rc != MCD_OK) return rc;
+    std::memcpy(out, w.h_out, (size_t)n_out * sizeof(double));
+    return MCD_OK;
+}
+
+int make_slot(int device, DeviceSlot* slot) {
+    MCD_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MCD_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MCD_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    slot->device = device;
+    MCD_HIP(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
+    return MCD_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* mcd_last_error(void) { return g_last_error.c_str(); }
+int mcd_abi_version(void) { return MCD_ABI_VERSION; }
+
+int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out) {
+    if (!out || n_dev <= 0) return fail(MCD_ERR_INVALID, "mcd_ctx_create: bad arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(MCD_ERR_NO_DEVICE, "no HIP device visible");
+    if (n_dev > count) return fail(MCD_ERR_NO_DEVICE, "more devices requested than visible");
+    std::unique_ptr<mcd_ctx> ctx(new (std::nothrow) mcd_ctx());
+    if (!ctx) return fail(MCD_ERR_INVALID, "out of memory");
+    ctx->slots.resize(n_dev);
+    std::vector<int> ids(n_dev);
+    for (int i = 0; i < n_dev; ++i) {
+        ids[i] = dev_ids ? dev_ids[i] : i;
+        int rc = make_slot(ids[i], &ctx->slots[i]);
+        if (rc != MCD_OK) return rc;
+    }
+    if (n_dev > 1) {
+        int rc = load_rccl();
+        if (rc != MCD_OK) return rc;
+        std::vector<ncclComm_t> comms(n_dev);
+        MCD_NCCL(g_rccl.CommInitAll(comms.data(), n_dev, ids.data()));
+        for (int i = 0; i < n_dev; ++i) ctx->slots[i].comm = comms[i];
+    }
+    ctx->rank = 0;
+    ctx->n_ranks = 1;
+    ctx->multi_process = false;
+    *out = ctx.release();
+    return MCD_OK;
+}
+
+int mcd_get_unique_id(void* out_id) {
+    if (!out_id) return fail(MCD_ERR_INVALID, "null id buffer");
+    static_assert(sizeof(ncclUniqueId) <= MCD_UNIQUE_ID_BYTES, "unique id does not fit");
+    int rc = load_rccl();
+    if (rc != MCD_OK) return rc;
+    ncclUniqueId id;
+    MCD_NCCL(g_rccl.GetUniqueId(&id));
+    std::memset(out_id, 0, MCD_UNIQUE_ID_BYTES);
+    std::memcpy(out_id, &id, sizeof id);
+    return MCD_OK;
+}
+
+int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id, mcd_ctx** out) {
+    if (!out || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(MCD_ERR_INVALID, "mcd_ctx_create_rank: bad arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(MCD_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= count) return fail(MCD_ERR_NO_DEVICE, "device index out of range");
+    std::unique_ptr<mcd_ctx> ctx(new (std::nothrow) mcd_ctx());
+    if (!ctx) return fail(MCD_ERR_INVALID, "out of memory");
+    ctx->slots.resize(1);
+    int rc = make_slot(device, &ctx->slots[0]);
+    if (rc != MCD_OK) return rc;
+    if (n_ranks > 1) {
+        if (!unique_id) return fail(MCD_ERR_INVALID, "unique_id required when n_ranks > 1");
+        rc = load_rccl();
+        if (rc != MCD_OK) return rc;
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof id);
+        MCD_NCCL(g_rccl.CommInitRank(&ctx->slots[0].comm, n_ranks, id, rank));
+    }
+    ctx->rank = rank;
+    ctx->n_ranks = n_ranks;
+    ctx->multi_process = true;
+    *out = ctx.release();
+    return MCD_OK;
+}
+
+int mcd_ctx_destroy(mcd_ctx* ctx) {
+    if (!ctx) return MCD_OK;
+    for (DeviceSlot& s : ctx->slots) {
+        (void)hipSetDevice(s.device);
+        if (s.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s.comm);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete ctx;
+    return MCD_OK;
+}
+
+int mcd_ctx_n_devices(const mcd_ctx* ctx) { return ctx ? (int)ctx->slots.size() : 0; }
+
+int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** out) {
+    if (!ctx || !d || !out) return fail(MCD_ERR_INVALID, "mcd_catalog_create: null argument");
+    if (d->n_stars < 0) return fail(MCD_ERR_INVALID, "negative n_stars");
+    if (d->model == MCD_MODEL_PROFILE || d->model == MCD_MODEL_PROFILE_BGGAUSS)
+        return fail(MCD_ERR_INVALID, "profile models are not part of ABI version 1");
+    if (d->model < 0 || d->model > MCD_MODEL_CONST_BGGAUSS) return fail(MCD_ERR_INVALID, "unknown model");
+    if (d->centre != MCD_CENTRE_FIXED && d->centre != MCD_CENTRE_FREE) return fail(MCD_ERR_INVALID, "unknown centre mode");
+    if (d->precision < MCD_F64 || d->precision > MCD_F32_ACC64) return fail(MCD_ERR_INVALID, "unknown precision");
+    if (d->n_stars > 0 && (!d->ra || !d->dec || !d->v || !d->verr)) return fail(MCD_ERR_INVALID, "missing ra/dec/v/verr column");
+    if (d->model == MCD_MODEL_CONST_BGFIXED && d->n_stars > 0 && (!d->lnlike_bg || !d->pmember))
+        return fail(MCD_ERR_INVALID, "background model needs lnlike_bg and pmember columns");
+    if (d->model == MCD_MODEL_CONST_BGGAUSS && d->n_stars > 0 && !d->density)
+        return fail(MCD_ERR_INVALID, "Gaussian-background model needs the density column");
+
+    std::unique_ptr<mcd_catalog> cat(new (std::nothrow) mcd_catalog());
+    if (!cat) return fail(MCD_ERR_INVALID, "out of memory");
+    cat->ctx = ctx;
+    cat->model = d->model;
+    cat->free_centre = d->centre == MCD_CENTRE_FREE;
+    cat->precision = d->precision;
+    cat->k = param_count(d->model, cat->free_centre);
+    cat->n_stars = d->n_stars;
+    if (const char* tw = std::getenv("MCD_TARGET_WAVES")) {
+        long v = std::atol(tw);
+        if (v > 0) cat->target_waves = v;
+    }
+    if (d->n_bins > 1) {
+        if (!d->bin_offsets) return fail(MCD_ERR_INVALID, "bin_offsets required when n_bins > 1");
+        cat->n_psets = d->n_bins;
+        cat->bin_offsets.assign(d->bin_offsets, d->bin_offsets + d->n_bins + 1);
+        if (cat->bin_offsets.front() != 0 || cat->bin_offsets.back() != d->n_stars)
+            return fail(MCD_ERR_INVALID, "bin_offsets must start at 0 and end at n_stars");
+        for (int64_t b = 0; b < d->n_bins; ++b)
+            if (cat->bin_offsets[b + 1] < cat->bin_offsets[b]) return fail(MCD_ERR_INVALID, "bin_offsets must be non-decreasing");
+    } else {
+        cat->n_psets = 1;
+        cat->bin_offsets = {0, d->n_stars};
+    }
+
+    // range statistics for the fast-path guard (runner.py:261: norm = verr*verr + sigma*sigma)
+    double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
+    bool finite = true;
+    for (int64_t i = 0; i < d->n_stars; ++i) {
+        const double e2 = d->verr[i] * d->verr[i];
+        const double av = std::fabs(d->v[i]);
+        if (!(std::isfinite(e2) && std::isfinite(av))) { finite = false; continue; }
+        e2_min = std::min(e2_min, e2);
+        e2_max = std::max(e2_max, e2);
+        v_abs = std::max(v_abs, av);
+    }
+    if (d->n_stars == 0) e2_min = 0.0;
+    cat->e2_min = e2_min; cat->e2_max = e2_max; cat->v_abs_max = v_abs; cat->stats_finite = finite;
+    if (d->model == MCD_MODEL_CONST_BGFIXED) {
+        bool ok = true;
+        for (int64_t i = 0; i < d->n_stars; ++i) {
+            const double b = d->lnlike_bg[i], pm = d->pmember[i];
+            if (!(std::isfinite(b) && b > -1.0e5 && b < 1.0e5 && pm >= 0.0 && pm <= 1.0)) { ok = false; break; }
+        }
+        cat->extras_ok = ok;
+    } else if (d->model == MCD_MODEL_CONST_BGGAUSS) {
+        double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
+        bool ok = true;
+        for (int64_t i = 0; i < d->n_stars; ++i) {
+            const double rho = d->density[i];
+            if (!(std::isfinite(rho) && rho >= 0.0)) { ok = false; break; }
+            r_min = std::min(r_min, rho); r_max = std::max(r_max, rho);
+        }
+        if (d->n_stars == 0) r_min = 0.0;
+        cat->extras_ok = ok; cat->rho_min = r_min; cat->rho_max = r_max;
+    }
+
+    // contiguous star shards, one per device of this process
+    const int n_dev = (int)ctx->slots.size();
+    cat->shards.resize(n_dev);
+    const int rec_bytes = mcd::record_bytes(cat->model, cat->free_centre, cat->precision);
+    for (int i = 0; i < n_dev; ++i) {
+        Shard& sh = cat->shards[i];
+        sh.slot = i;
+        sh.star_begin = d->n_stars * i / n_dev;
+        sh.n = d->n_stars * (i + 1) / n_dev - sh.star_begin;
+        const DeviceSlot& slot = ctx->slots[i];
+        MCD_HIP(hipSetDevice(slot.device));
+        MCD_HIP(hipEventCreate(&sh.ev_begin));
+        MCD_HIP(hipEventCreate(&sh.ev_k0));
+        MCD_HIP(hipEventCreate(&sh.ev_k1));
+        MCD_HIP(hipEventCreate(&sh.ev_end));
+        MCD_HIP(hipMalloc(&sh.records, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256)));  // slack for wide scalar loads
+        MCD_HIP(hipMemsetAsync(sh.records, 0, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256), slot.stream));
+        if (sh.n == 0) continue;
+        // raw columns -> device scratch -> packed records (device-side trig), scratch freed afterwards
+        const double* host_cols[7] = {d->ra, d->dec, d->v, d->verr, d->lnlike_bg, d->pmember, d->density};
+        double* dev_cols[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        for (int c = 0; c < 7; ++c) {
+            if (!host_cols[c]) continue;
+            MCD_HIP(hipMalloc(&dev_cols[c], (size_t)sh.n * sizeof(double)));
+            MCD_HIP(hipMemcpyAsync(dev_cols[c], host_cols[c] + sh.star_begin, (size_t)sh.n * sizeof(double),
+                                   hipMemcpyHostToDevice, slot.stream));
+        }
+        mcd::RawColumns raw{dev_cols[0], dev_cols[1], dev_cols[2], dev_cols[3], dev_cols[4], dev_cols[5], dev_cols[6]};
+        MCD_HIP(mcd::launch_prepare_records(slot.stream, raw, sh.n, cat->model, cat->free_centre, cat->precision,
+                                            d->ra_center, d->dec_center, sh.records));
+        MCD_HIP(hipStreamSynchronize(slot.stream));
+        for (int c = 0; c < 7; ++c)
+            if (dev_cols[c]) MCD_HIP(hipFree(dev_cols[c]));
+    }
+    *out = cat.release();
+    return MCD_OK;
+}
+
+int mcd_catalog_destroy(mcd_catalog* cat) {
+    if (!cat) return MCD_OK;
+    for (Shard& sh : cat->shards) {
+        (void)hipSetDevice(cat->ctx->slots[sh.slot].device);
+        (void)hipStreamSynchronize(cat->ctx->slots[sh.slot].stream);
+        for (auto& kv : sh.work) free_workset(kv.second);
+        if (sh.records) (void)hipFree(sh.records);
+        if (sh.ev_begin) (void)hipEventDestroy(sh.ev_begin);
+        if (sh.ev_k0) (void)hipEventDestroy(sh.ev_k0);
+        if (sh.ev_k1) (void)hipEventDestroy(sh.ev_k1);
+        if (sh.ev_end) (void)hipEventDestroy(sh.ev_end);
+    }
+    delete cat;
+    return MCD_OK;
+}
+
+int mcd_catalog_param_count(const mcd_catalog* cat) { return cat ? cat->k : MCD_ERR_INVALID; }
+int64_t mcd_catalog_n_stars(const mcd_catalog* cat) { return cat ? cat->n_stars : MCD_ERR_INVALID; }
+int64_t mcd_catalog_n_outputs(const mcd_catalog* cat, int64_t n_walkers) {
+    return cat ? cat->n_psets * n_walkers : MCD_ERR_INVALID;
+}
+
+int mcd_params_upload(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params) {
+    return stage_params(cat, n_walkers, k, params);
+}
+
+int mcd_loglike_enqueue(mcd_catalog* cat) { return enqueue(cat); }
+int mcd_loglike_fetch(mcd_catalog* cat, double* out) { return fetch(cat, out); }
+int mcd_sync(mcd_catalog* cat) { return sync_all(cat); }
+
+int mcd_loglike_batch(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, double* out) {
+    if (!out) return fail(MCD_ERR_INVALID, "null output");
+    int rc = stage_params(cat, n_walkers, k, params);
+    if (rc != MCD_OK) return rc;
+    rc = enqueue(cat);
+    if (rc != MCD_OK) return rc;
+    return fetch(cat, out);
+}
+
+int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* out) {
+    if (!cat || !params || !out) return fail(MCD_ERR_INVALID, "mcd_membership: null argument");
+    if (cat->model != MCD_MODEL_CONST_BGGAUSS) return fail(MCD_ERR_INVALID, "membership needs a Gaussian-background catalogue");
+    if (cat->n_psets != 1) return fail(MCD_ERR_INVALID, "membership is defined for un-binned catalogues");
+    if (k != cat->k) return fail(MCD_ERR_INVALID, "parameter row has the wrong number of columns");
+    const size_t term_bytes = cat->precision == MCD_F64 ? 8 : 4;
+    for (Shard& sh : cat->shards) {
+        if (sh.n == 0) continue;
+        const DeviceSlot& slot = cat->ctx->slots[sh.slot];
+        MCD_HIP(hipSetDevice(slot.device));
+        double* d_p = nullptr; void* d_w = nullptr; double* d_o = nullptr;
+        MCD_HIP(hipMalloc(&d_p, k * sizeof(double)));
+        MCD_HIP(hipMalloc(&d_w, mcd::KD * term_bytes));
+        MCD_HIP(hipMalloc(&d_o, (size_t)sh.n * sizeof(double)));
+        MCD_HIP(hipMemcpyAsync(d_p, params, k * sizeof(double), hipMemcpyHostToDevice, slot.stream));
+        MCD_HIP(mcd::launch_prepare_walkers(slot.stream, d_p, 1, k, cat->model, cat->free_centre, cat->precision, d_w));
+        mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, false};
+        MCD_HIP(mcd::launch_membership(slot.stream, shape, sh.records, sh.n, d_w, d_o));
+        MCD_HIP(hipMemcpyAsync(out + sh.star_begin, d_o, (size_t)sh.n * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
+        MCD_HIP(hipStreamSynchronize(slot.stream));
+        MCD_HIP(hipFree(d_p)); MCD_HIP(hipFree(d_w)); MCD_HIP(hipFree(d_o));
+    }
+    return MCD_OK;
+}
+
+int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
+    if (!cat || !key) return fail(MCD_ERR_INVALID, "mcd_set_option: null argument");
+    if (!std::strcmp(key, "timing")) { cat->timing = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "fast_path")) { cat->allow_fast = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "target_waves")) {
+        if (value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");
+        int rc = sync_all(cat);
+        if (rc != MCD_OK) return rc;
+        cat->target_waves = value;
+        for (Shard& sh : cat->shards) {            // chunk tables depend on it: rebuild lazily
+            (void)hipSetDevice(cat->ctx->slots[sh.slot].device);
+            for (auto& kv : sh.work) free_workset(kv.second);
+            sh.work.clear();
+        }
+        cat->cur_walkers = 0;
+        return MCD_OK;
+    }
+    return fail(MCD_ERR_INVALID, std::string("unknown option: ") + key);
+}
+
+double mcd_last_kernel_ms(const mcd_catalog* cat) { return cat ? cat->last_kernel_ms : -1.0; }
+double mcd_last_device_ms(const mcd_catalog* cat) { return cat ? cat->last_device_ms : -1.0; }
+
+int mcd_last_launch_info(const mcd_catalog* cat, int64_t* n_workgroups, int32_t* walker_tile, int64_t* n_chunks,
+                         int32_t* record_bytes) {
+    if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
+    if (n_workgroups) *n_workgroups = cat->last_grid;
+    if (walker_tile) *walker_tile = 64;
+    if (n_chunks) *n_chunks = cat->last_chunks;
+    if (record_bytes) *record_bytes = mcd::record_bytes(cat->model, cat->free_centre, cat->precision);
+    return MCD_OK;
+}
+
+}  // extern "C"

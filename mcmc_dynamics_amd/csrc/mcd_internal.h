@@ -1,0 +1,56 @@
+// mcd_internal.h -- declarations shared by the kernels (mcd_kernels.hip) and the C-ABI (mcd_api.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mcd {
+
+// One unit of work of the main kernel: a contiguous run of stars that all use parameter set `pset`.
+// A wave evaluates one chunk for 64 walkers (lane = walker; star records arrive through the scalar
+// cache as wave-uniform loads).
+struct Chunk {
+    int64_t begin;   // first star (record index on this device)
+    int32_t count;   // stars in the chunk
+    int32_t pset;    // parameter set (radial bin) the stars belong to
+};
+
+struct LaunchShape {
+    int model;        // mcd::Model
+    bool free_centre;
+    int precision;    // mcd_precision
+    bool fast;        // product/fraction-tree path allowed (range guard passed)
+};
+
+// raw per-star columns on the device (float64), consumed once by prepare_records
+struct RawColumns {
+    const double* ra;
+    const double* dec;
+    const double* v;
+    const double* verr;
+    const double* lnbg;
+    const double* pmember;
+    const double* density;
+};
+
+hipError_t launch_prepare_records(hipStream_t s, const RawColumns& raw, int64_t n, int model, bool free_centre,
+                                  int precision, double ra_c_deg, double dec_c_deg, void* records);
+
+// params [n_rows][k] (float64, reference order) -> derived walker constants [n_rows][KD] in term precision
+hipError_t launch_prepare_walkers(hipStream_t s, const double* params, int64_t n_rows, int k, int model,
+                                  bool free_centre, int precision, void* wpar);
+
+hipError_t launch_loglike(hipStream_t s, const LaunchShape& shape, const void* records, const Chunk* chunks,
+                          int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers);
+
+// out[pset][w] = sum over the chunks of pset of partials[w][chunk]  (fixed order)
+hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* pset_chunk_offsets,
+                         int64_t n_psets, int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers,
+                         double* out);
+
+hipError_t launch_membership(hipStream_t s, const LaunchShape& shape, const void* records, int64_t n,
+                             const void* wpar_row, double* out);
+
+int record_bytes(int model, bool free_centre, int precision);
+
+}  // namespace mcd

@@ -1,0 +1,302 @@
+// mcd_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the per-walker log-likelihood hot path.
+//
+// Work decomposition:
+//   * lane  = walker.  A 64-lane wave evaluates 64 walkers against one chunk of stars.
+//   * star records are wave-uniform: the compiler turns the record reads into s_load_dwordxN
+//     (scalar cache, broadcast to all lanes for free as SGPR operands of the f64 VALU ops), so one
+//     32..64-byte record load feeds 64 star-walker terms and no LDS/VGPR staging is spent on it.
+//   * each wave keeps its walkers' running sums in registers; no cross-lane traffic in the hot loop.
+//   * per-(walker, chunk) partials go to HBM; a second kernel reduces them with a fixed tree
+//     (wave shuffle + LDS), so results are bitwise reproducible.  No float atomics anywhere.
+//
+// The kernel is bound by the f64 VALU issue rate, not by HBM: the catalogue (32..64 B/star) is read
+// once per 64..256 walkers.  MFMA has nothing to offer here (no contraction).
+#include "mcd_internal.h"
+#include "mcd_math.h"
+
+namespace mcd {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;               // 4 waves: one per SIMD of a CU
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+constexpr double kDeg2Rad = 0.017453292519943295769;
+constexpr double kR0Arcmin = 3437.7467707849392526;   // 10800 / pi, calc_xy_offset.py:11
+
+// ------------------------------------------------------------------------------------------------
+// star prep: raw float64 columns -> packed records (one thread per star; runs once per catalogue)
+template <class T>
+__global__ __launch_bounds__(kBlock) void prepare_records_kernel(RawColumns raw, int64_t n, int model,
+                                                                  int free_centre, double ra_c, double dec_c,
+                                                                  T* __restrict__ rec) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int nd = record_doubles(model, free_centre != 0);
+    T* r = rec + i * nd;
+    const double verr = raw.verr[i];
+    r[0] = (T)raw.v[i];
+    r[1] = (T)(verr * verr);                                        // runner.py:261 (verr * verr)
+    const double ra = raw.ra[i], dec = raw.dec[i];
+    int k;
+    if (free_centre) {
+        double sa, ca, sd, cd;
+        sincos(ra * kDeg2Rad, &sa, &ca);
+        sincos(dec * kDeg2Rad, &sd, &cd);
+        r[2] = (T)sa; r[3] = (T)ca; r[4] = (T)sd; r[5] = (T)cd;
+        k = 6;
+    } else {
+        // calc_xy_offset.py:30-31 followed by arctan2 (constant.py:107), reduced to sin/cos(theta)
+        const double dra = (ra - ra_c) * kDeg2Rad;
+        const double dec_r = dec * kDeg2Rad, dec_cr = dec_c * kDeg2Rad;
+        const double dx = -kR0Arcmin * cos(dec_r) * sin(dra);
+        const double dy = kR0Arcmin * (sin(dec_r) * cos(dec_cr) - cos(dec_r) * sin(dec_cr) * cos(dra));
+        const double rr = hypot(dx, dy);
+        double s, c;
+        if (rr > 0.0) { s = dy / rr; c = dx / rr; }
+        else { s = 0.0; c = signbit(dx) ? -1.0 : 1.0; }            // numpy arctan2(+0, -0) = pi
+        r[2] = (T)s; r[3] = (T)c;
+        k = 4;
+    }
+    if (model == MODEL_BGFIXED) {
+        const double b = raw.lnbg[i], pm = raw.pmember[i];
+        r[k] = (T)b; r[k + 1] = (T)pm; r[k + 2] = (T)(1.0 - pm); r[k + 3] = (T)(-(b + kHalfLn2Pi));
+    } else if (model == MODEL_BGGAUSS) { r[k] = (T)raw.density[i]; r[k + 1] = (T)0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// walker prep: resolved parameter rows (reference order) -> derived constants, one thread per row
+template <class T>
+__global__ __launch_bounds__(kBlock) void prepare_walkers_kernel(const double* __restrict__ params, int64_t n_rows,
+                                                                  int k, int model, int free_centre,
+                                                                  T* __restrict__ wpar) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_rows) return;
+    const double* p = params + i * k;
+    T* w = wpar + i * KD;
+    const double sigma = p[1];
+    w[W_VSYS] = (T)p[0];
+    w[W_S2] = (T)(sigma * sigma);                                   // runner.py:261 (sigma_los * sigma_los)
+    w[W_VX] = (T)p[2];
+    w[W_VY] = (T)p[3];
+    int j = 4;
+    double sac = 0, cac = 1, sdc = 0, cdc = 1;
+    if (free_centre) {
+        sincos(p[4] * kDeg2Rad, &sac, &cac);
+        sincos(p[5] * kDeg2Rad, &sdc, &cdc);
+        j = 6;
+    }
+    w[W_SAC] = (T)sac; w[W_CAC] = (T)cac; w[W_SDC] = (T)sdc; w[W_CDC] = (T)cdc;
+    double vb = 0, sb = 0, fb = 0;
+    if (model == MODEL_BGGAUSS) { vb = p[j]; sb = p[j + 1]; fb = p[j + 2]; }
+    w[W_VB] = (T)vb; w[W_SB2] = (T)(sb * sb); w[W_FB] = (T)fb; w[W_LNF] = (T)0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel (the per-chunk arithmetic lives in mcd_math.h: chunk_loglike)
+template <int MODEL, bool FREE, class T, class A, bool FAST>
+__global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ recs,
+                                                          const Chunk* __restrict__ chunks,
+                                                          const T* __restrict__ wpar,
+                                                          double* __restrict__ partials, int64_t n_tasks,
+                                                          int n_wtiles, int64_t n_walkers, int64_t n_chunks) {
+    constexpr int ND = record_doubles(MODEL, FREE);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave;      // wave-uniform
+    if (task >= n_tasks) return;
+    const int64_t chunk_id = task / n_wtiles;
+    const int wtile = (int)(task - chunk_id * n_wtiles);
+    const Chunk ch = chunks[chunk_id];                                      // scalar load
+    const int64_t w_raw = (int64_t)wtile * kWave + lane;
+    const bool active = w_raw < n_walkers;
+    const int64_t w_idx = active ? w_raw : n_walkers - 1;                   // idle lanes shadow the last walker
+
+    const T* __restrict__ wp = wpar + ((int64_t)ch.pset * n_walkers + w_idx) * KD;
+    WalkerConsts<T> w;
+    w.vsys = wp[W_VSYS]; w.s2 = wp[W_S2]; w.vx = wp[W_VX]; w.vy = wp[W_VY];
+    if (FREE) { w.sac = wp[W_SAC]; w.cac = wp[W_CAC]; w.sdc = wp[W_SDC]; w.cdc = wp[W_CDC]; }
+    if (MODEL == MODEL_BGGAUSS) { w.vb = wp[W_VB]; w.sb2 = wp[W_SB2]; w.fb = wp[W_FB]; }
+
+    // wave-uniform record pointer: the reads inside chunk_loglike become scalar loads
+    const double result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w);
+    if (active) partials[w_raw * n_chunks + chunk_id] = result;
+}
+
+// ------------------------------------------------------------------------------------------------
+// final reduction, wide form: one 256-thread block per output (pset, walker); contiguous partials
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    return x;
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_wide_kernel(const double* __restrict__ partials,
+                                                              const int64_t* __restrict__ offs, int64_t n_chunks,
+                                                              int64_t n_walkers, double* __restrict__ out) {
+    __shared__ double lds[kWavesPerBlock];
+    const int64_t o = blockIdx.x;
+    const int64_t pset = o / n_walkers, w = o - pset * n_walkers;
+    const int64_t c0 = offs[pset], c1 = offs[pset + 1];
+    const double* __restrict__ row = partials + w * n_chunks;
+    double acc = 0.0;
+    for (int64_t c = c0 + threadIdx.x; c < c1; c += kBlock) acc += row[c];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[o] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// narrow form: one thread per output, few chunks per parameter set (radial bins)
+__global__ __launch_bounds__(kBlock) void reduce_narrow_kernel(const double* __restrict__ partials,
+                                                                const int64_t* __restrict__ offs, int64_t n_psets,
+                                                                int64_t n_chunks, int64_t n_walkers,
+                                                                double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_psets * n_walkers) return;
+    const int64_t w = t / n_psets, pset = t - w * n_psets;       // pset fastest: neighbouring chunks
+    const int64_t c0 = offs[pset], c1 = offs[pset + 1];
+    const double* __restrict__ row = partials + w * n_chunks;
+    double acc = 0.0;
+    for (int64_t c = c0; c < c1; ++c) acc += row[c];
+    out[pset * n_walkers + w] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// membership probabilities (constant.py:366-374): one thread per star, one parameter row
+template <bool FREE, class T>
+__global__ __launch_bounds__(kBlock) void membership_kernel(const T* __restrict__ recs, int64_t n,
+                                                             const T* __restrict__ wp, double* __restrict__ out) {
+    constexpr int ND = record_doubles(MODEL_BGGAUSS, FREE);
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    WalkerConsts<T> w;
+    w.vsys = wp[W_VSYS]; w.s2 = wp[W_S2]; w.vx = wp[W_VX]; w.vy = wp[W_VY];
+    w.sac = wp[W_SAC]; w.cac = wp[W_CAC]; w.sdc = wp[W_SDC]; w.cdc = wp[W_CDC];
+    w.vb = wp[W_VB]; w.sb2 = wp[W_SB2]; w.fb = wp[W_FB];
+    const T* r = recs + i * ND;
+    T d, nrm;
+    star_d_n<T, FREE>(r, w, d, nrm);
+    const T lc = gauss_lnl(d, nrm);
+    const T lb = gauss_lnl(r[0] - w.vb, r[1] + w.sb2);
+    const T rho = r[FREE ? 6 : 4];
+    const T m = rho / (rho + w.fb);
+    const T ec = m * exp_(lc), eb = (T(1) - m) * exp_(lb);
+    out[i] = (double)(ec / (ec + eb));
+}
+
+template <int MODEL, bool FREE, class T, class A, bool FAST>
+hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, int64_t n_chunks, const void* wpar,
+                      double* partials, int64_t n_walkers) {
+    const int n_wtiles = (int)((n_walkers + kWave - 1) / kWave);
+    const int64_t n_tasks = n_chunks * n_wtiles;
+    const int64_t grid = (n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST>), dim3((unsigned)grid), dim3(kBlock), 0, s,
+                       (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks);
+    return hipGetLastError();
+}
+
+template <int MODEL, bool FREE>
+hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* records, const Chunk* chunks,
+                            int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers) {
+    switch (sh.precision) {
+        case 0:
+            if (sh.fast)
+                return launch_one<MODEL, FREE, double, double, true>(s, records, chunks, n_chunks, wpar, partials,
+                                                                     n_walkers);
+            return launch_one<MODEL, FREE, double, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
+        case 1:
+            return launch_one<MODEL, FREE, float, float, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
+        case 2:
+            return launch_one<MODEL, FREE, float, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+int record_bytes(int model, bool free_centre, int precision) {
+    return record_doubles(model, free_centre) * (precision == 0 ? 8 : 4);
+}
+
+hipError_t launch_prepare_records(hipStream_t s, const RawColumns& raw, int64_t n, int model, bool free_centre,
+                                  int precision, double ra_c_deg, double dec_c_deg, void* records) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    if (precision == 0)
+        hipLaunchKernelGGL(prepare_records_kernel<double>, dim3(grid), dim3(kBlock), 0, s, raw, n, model,
+                           (int)free_centre, ra_c_deg, dec_c_deg, (double*)records);
+    else
+        hipLaunchKernelGGL(prepare_records_kernel<float>, dim3(grid), dim3(kBlock), 0, s, raw, n, model,
+                           (int)free_centre, ra_c_deg, dec_c_deg, (float*)records);
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare_walkers(hipStream_t s, const double* params, int64_t n_rows, int k, int model,
+                                  bool free_centre, int precision, void* wpar) {
+    if (n_rows <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_rows + kBlock - 1) / kBlock);
+    if (precision == 0)
+        hipLaunchKernelGGL(prepare_walkers_kernel<double>, dim3(grid), dim3(kBlock), 0, s, params, n_rows, k, model,
+                           (int)free_centre, (double*)wpar);
+    else
+        hipLaunchKernelGGL(prepare_walkers_kernel<float>, dim3(grid), dim3(kBlock), 0, s, params, n_rows, k, model,
+                           (int)free_centre, (float*)wpar);
+    return hipGetLastError();
+}
+
+hipError_t launch_loglike(hipStream_t s, const LaunchShape& sh, const void* records, const Chunk* chunks,
+                          int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers) {
+#define MCD_DISPATCH(M)                                                                                          \
+    case M:                                                                                                      \
+        return sh.free_centre ? launch_precision<M, true>(s, sh, records, chunks, n_chunks, wpar, partials, n_walkers) \
+                              : launch_precision<M, false>(s, sh, records, chunks, n_chunks, wpar, partials, n_walkers);
+    switch (sh.model) {
+        MCD_DISPATCH(MODEL_CONST)
+        MCD_DISPATCH(MODEL_BGFIXED)
+        MCD_DISPATCH(MODEL_BGGAUSS)
+    }
+#undef MCD_DISPATCH
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* offs, int64_t n_psets,
+                         int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers, double* out) {
+    const int64_t n_out = n_psets * n_walkers;
+    if (n_out <= 0) return hipSuccess;
+    if (max_chunks_per_pset > 16) {
+        hipLaunchKernelGGL(reduce_wide_kernel, dim3((unsigned)n_out), dim3(kBlock), 0, s, partials, offs, n_chunks,
+                           n_walkers, out);
+    } else {
+        const unsigned grid = (unsigned)((n_out + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(reduce_narrow_kernel, dim3(grid), dim3(kBlock), 0, s, partials, offs, n_psets, n_chunks,
+                           n_walkers, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_membership(hipStream_t s, const LaunchShape& sh, const void* records, int64_t n,
+                             const void* wpar_row, double* out) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    if (sh.precision == 0) {
+        if (sh.free_centre)
+            hipLaunchKernelGGL((membership_kernel<true, double>), dim3(grid), dim3(kBlock), 0, s,
+                               (const double*)records, n, (const double*)wpar_row, out);
+        else
+            hipLaunchKernelGGL((membership_kernel<false, double>), dim3(grid), dim3(kBlock), 0, s,
+                               (const double*)records, n, (const double*)wpar_row, out);
+    } else {
+        if (sh.free_centre)
+            hipLaunchKernelGGL((membership_kernel<true, float>), dim3(grid), dim3(kBlock), 0, s,
+                               (const float*)records, n, (const float*)wpar_row, out);
+        else
+            hipLaunchKernelGGL((membership_kernel<false, float>), dim3(grid), dim3(kBlock), 0, s,
+                               (const float*)records, n, (const float*)wpar_row, out);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mcd

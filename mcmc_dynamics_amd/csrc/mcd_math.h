@@ -1,0 +1,439 @@
+// mcd_math.h -- per-term arithmetic of the log-likelihood kernels.
+//
+// Written once as host+device inline code so that the exact expression trees the gfx950 kernels
+// execute can also be compiled for the CPU by tests/emul (test infrastructure only; the product
+// never runs this on the CPU).
+//
+// Reference formulas (skamann/mcmc-dynamics):
+//   v_los  = v_sys + v_max sin(theta - theta_0)                      analysis/constant.py:107-111
+//          = v_sys + v_maxx sin(theta) - v_maxy cos(theta)
+//   norm   = verr^2 + sigma^2 ; exponent = -1/2 (v - v_los)^2 / norm  analysis/runner.py:261-262
+//   no background : lnL = -1/2 sum log(2 pi norm) + sum exponent      analysis/runner.py:269-271
+//   background    : per-star log-sum-exp mixture                      analysis/runner.py:280-286
+//   GB            : per-walker Gaussian background + density prior    analysis/constant.py:326-364
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define MCD_HD __host__ __device__ __forceinline__
+#else
+#define MCD_HD inline
+#endif
+
+namespace mcd {
+
+constexpr double kLn2 = 0.693147180559945309417232121458;
+constexpr double kLn2Pi = 1.837877066409345483560659472811;   // log(2 pi)
+constexpr double kHalfLn2Pi = 0.918938533204672741780329736406;
+
+// Derived per-walker constants (one row of KD doubles per (parameter set, walker)), produced by the
+// walker-prep kernel from the resolved parameter table.
+enum WalkerSlot : int {
+    W_VSYS = 0, W_S2 = 1, W_VX = 2, W_VY = 3,       // v_sys, sigma_max^2, v_maxx, v_maxy
+    W_SAC = 4, W_CAC = 5, W_SDC = 6, W_CDC = 7,     // sin/cos(ra_center), sin/cos(dec_center)
+    W_VB = 8, W_SB2 = 9, W_FB = 10, W_LNF = 11,     // v_back, sigma_back^2, f_back, (spare)
+    KD = 12
+};
+
+// Star record slots (doubles).  Fixed centre: v, e2, sin(theta), cos(theta), extras.
+// Free centre: v, e2, sin(ra), cos(ra), sin(dec), cos(dec), extras.
+// extras: BGFIXED -> lnlike_bg, pmember, 1 - pmember, -(lnlike_bg + 1/2 log 2pi) ; BGGAUSS -> density, (pad)
+enum Model : int { MODEL_CONST = 0, MODEL_BGFIXED = 1, MODEL_BGGAUSS = 2 };
+
+MCD_HD constexpr int record_doubles(int model, bool free_centre) {
+    return (free_centre ? 6 : 4) + (model == MODEL_CONST ? 0 : (model == MODEL_BGFIXED ? 4 : 2));
+}
+
+template <class T>
+MCD_HD T fma_(T a, T b, T c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return std::fma(a, b, c);
+#endif
+}
+MCD_HD float fma_(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return std::fmaf(a, b, c);
+#endif
+}
+
+// sin(theta), cos(theta) of the position angle about a walker's centre from the star's and the
+// centre's sines/cosines (angle-addition form of calc_xy_offset.py:30-31 followed by
+// arctan2, constant.py:106-107; the r0 factor cancels).  r == 0 follows numpy's arctan2(+0, -0) = pi.
+template <class T>
+MCD_HD void free_centre_geometry(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T cdc, T& s, T& c) {
+    T sin_dra = fma_(sa, cac, -(ca * sac));
+    T cos_dra = fma_(ca, cac, sa * sac);
+    T x = -(cd * sin_dra);
+    T y = fma_(sd, cdc, -(cd * sdc * cos_dra));
+    T r2 = fma_(x, x, y * y);
+    if (r2 > T(0)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        T inv = T(1) / sqrt(r2);
+#else
+        T inv = T(1) / std::sqrt(r2);
+#endif
+        s = y * inv;
+        c = x * inv;
+    } else {
+        s = T(0);
+        c = std::signbit(x) ? T(-1) : T(1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sum of logs as the log of a running product with explicit exponent tracking:
+//   sum_i log(x_i) = log(prod_i m_i) + ln2 * sum_i e_i .
+// One multiply per factor instead of one log per factor; the product's relative error grows by
+// 2^-53 per multiply, i.e. the absolute error of the log sum is <= 1.1e-16 per term -- tighter than
+// summing individually rounded logs.
+struct LogProduct {
+    double p;
+    int64_t e;
+    MCD_HD void init() { p = 1.0; e = 0; }
+    MCD_HD void mul(double x) { p *= x; }            // caller keeps |log2 p| < ~1000 between rescales
+    MCD_HD void rescale() {
+        int ex;
+#if defined(__HIP_DEVICE_COMPILE__)
+        p = __builtin_frexp(p, &ex);
+#else
+        p = std::frexp(p, &ex);
+#endif
+        e += ex;
+    }
+    MCD_HD void mul_any(double x) {                  // any positive finite x: split first
+        int ex;
+#if defined(__HIP_DEVICE_COMPILE__)
+        double m = __builtin_frexp(x, &ex);
+#else
+        double m = std::frexp(x, &ex);
+#endif
+        p *= m;
+        e += ex;
+    }
+    MCD_HD double value() {
+        rescale();
+#if defined(__HIP_DEVICE_COMPILE__)
+        return fma_((double)e, kLn2, log(p));
+#else
+        return fma_((double)e, kLn2, std::log(p));
+#endif
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// MODEL_CONST, fast path: G stars of one walker reduced to ONE division and ONE product factor.
+//   sum_j q_j / n_j = NUM / DEN,  DEN = prod_j n_j,  built as a balanced tree of (num, den) pairs:
+//   (a, m) (+) (b, n) = (a n + b m, m n).
+// Valid while DEN and NUM stay in range: host guards 2^-60 <= n <= 2^60 and q < 2^120 for G = 8.
+struct Frac { double num, den; };
+MCD_HD Frac frac_leaf2(double q0, double n0, double q1, double n1) {
+    Frac f;
+    f.den = n0 * n1;
+    f.num = fma_(q1, n0, q0 * n1);
+    return f;
+}
+MCD_HD Frac frac_join(Frac a, Frac b) {
+    Frac f;
+    f.den = a.den * b.den;
+    f.num = fma_(b.num, a.den, a.num * b.den);
+    return f;
+}
+
+struct ConstAcc {          // accumulators of one walker over one chunk (MODEL_CONST)
+    double q;              // sum (v - v_los)^2 / norm
+    LogProduct l;          // sum log(norm)
+    MCD_HD void init() { q = 0.0; l.init(); }
+    MCD_HD void add8(const double* qq, const double* nn) {
+        Frac f = frac_join(frac_join(frac_leaf2(qq[0], nn[0], qq[1], nn[1]), frac_leaf2(qq[2], nn[2], qq[3], nn[3])),
+                           frac_join(frac_leaf2(qq[4], nn[4], qq[5], nn[5]), frac_leaf2(qq[6], nn[6], qq[7], nn[7])));
+        q += f.num / f.den;
+        l.mul(f.den);
+        l.rescale();
+    }
+    MCD_HD void add1(double q1, double n1) {
+        q += q1 / n1;
+        l.mul_any(n1);
+    }
+    // lnL contribution of `count` stars: -1/2 (count log 2pi + sum log n + sum q/n)
+    MCD_HD double finish(int64_t count) { return -0.5 * (fma_((double)count, kLn2Pi, l.value()) + q); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Plain per-term forms (robust path and mixtures): one log / exp per term as written in the reference.
+template <class T> MCD_HD T log_(T x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return log(x);
+#else
+    return std::log(x);
+#endif
+}
+template <class T> MCD_HD T exp_(T x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return exp(x);
+#else
+    return std::exp(x);
+#endif
+}
+template <class T> MCD_HD T max_(T a, T b) { return a > b ? a : b; }
+
+// lnL_member of runner.py:280 / lnlike_cluster of constant.py:362
+template <class T>
+MCD_HD T gauss_lnl(T d, T n) {
+    return T(-0.5) * (log_(n) + T(kLn2Pi) + d * d / n);
+}
+
+// per-star mixture of runner.py:282-284 / constant.py:320-323
+template <class T>
+MCD_HD T mixture_lnl(T m, T b, T p) {
+    T mx = max_(m, b);
+    return mx + log_(p * exp_(m - mx) + (T(1) - p) * exp_(b - mx));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast mixture paths (f64): no log, no divide per term.
+//   exp(-1/2 d^2/n) / sqrt(n)  is formed from g = n^(-1/2)  (v_rsq_f64 + two Newton steps)
+//   and one exp whose argument is <= 0 or exponent-clamped; the per-star mixture value y_i > 0 is
+//   folded into a LogProduct:  sum_i log y_i = log prod_i y_i.
+
+MCD_HD double rsqrt_nr(double n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(n);
+#else
+    double y = 1.0 / std::sqrt(n);
+#endif
+    // y <- y + y (1 - n y^2) / 2, twice: 2^-23 -> 2^-45 -> full f64
+    double e = fma_(-(n * y), y, 1.0);
+    y = fma_(y, 0.5 * e, y);
+    e = fma_(-(n * y), y, 1.0);
+    y = fma_(y, 0.5 * e, y);
+    return y;
+}
+
+// e^u = 2^k e^r with k = rint(u / ln 2), |r| <= ln2 / 2; returns the mantissa part e^r and k.
+// Taylor to r^13 / 13!: truncation error 4e-18 on the reduced range.
+MCD_HD double exp_split(double u, int& k_out) {
+    constexpr double kLog2e = 1.442695040888963407359924681;
+    constexpr double kLn2Hi = 6.93147180369123816490e-01;    // high 32 bits of ln 2 (k * hi is exact)
+    constexpr double kLn2Lo = 1.90821492927058770002e-10;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double kf = __builtin_rint(u * kLog2e);
+#else
+    const double kf = std::nearbyint(u * kLog2e);
+#endif
+    double r = fma_(-kf, kLn2Hi, u);
+    r = fma_(-kf, kLn2Lo, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma_(p, r, 1.0 / 479001600.0);
+    p = fma_(p, r, 1.0 / 39916800.0);
+    p = fma_(p, r, 1.0 / 3628800.0);
+    p = fma_(p, r, 1.0 / 362880.0);
+    p = fma_(p, r, 1.0 / 40320.0);
+    p = fma_(p, r, 1.0 / 5040.0);
+    p = fma_(p, r, 1.0 / 720.0);
+    p = fma_(p, r, 1.0 / 120.0);
+    p = fma_(p, r, 1.0 / 24.0);
+    p = fma_(p, r, 1.0 / 6.0);
+    p = fma_(p, r, 0.5);
+    p = fma_(p, r, 1.0);
+    p = fma_(p, r, 1.0);
+    k_out = (int)kf;
+    return p;
+}
+
+MCD_HD double ldexp_(double x, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_ldexp(x, k);
+#else
+    return std::ldexp(x, k);
+#endif
+}
+MCD_HD double clamp_(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// MODEL_BGFIXED: lnL_i = b_i + log((1 - p_i) + p_i t_i),  t_i = exp(m_i - b_i) = g exp(-1/2 q g^2 - b'_i),
+// b'_i = b_i + 1/2 log 2pi  (the record carries nbp = -b'_i).  Same value as runner.py:280-286.
+struct BgFixedAcc {
+    double sum_b;          // sum b_i
+    LogProduct l;          // sum log y_i
+    MCD_HD void init() { sum_b = 0.0; l.init(); }
+    MCD_HD void add(double d, double n, double b, double p, double omp, double nbp) {
+        const double g = rsqrt_nr(n);
+        const double w = (d * d) * (g * g);
+        double u = fma_(-0.5, w, nbp);
+        u = clamp_(u, -1.0e6, 1.0e6);            // keeps k inside int range; exactness unaffected (see below)
+        int k;
+        const double er = exp_split(u, k);
+        const double x = p * (g * er);
+        // y = (1 - p) + x 2^k.  Exponents beyond +-1000 are carried in the integer part of the product:
+        // for k > 1000 the (1 - p) term is below 2^-900 of y and drops out exactly as it would in f64.
+        const int kc = k < -1000 ? -1000 : (k > 1000 ? 1000 : k);
+        const double y = omp + ldexp_(x, kc);
+        l.mul_any(y);
+        l.e += (k > kc) ? (k - kc) : 0;
+        sum_b += b;
+    }
+    MCD_HD void rescale() { l.rescale(); }
+    MCD_HD double finish() { return sum_b + l.value(); }
+};
+
+// MODEL_BGGAUSS (constant.py:320-364):
+//   lnL_i = log( mu_i C_i + (1 - mu_i) B_i ),  mu_i = rho_i / (rho_i + f)
+//         = -1/2 log 2pi - log(rho_i + f) - 1/2 min(w, wb) + log y_i
+//   y_i   = rho g + f gb e^{-delta}   (w <= wb)   or   rho g e^{-delta} + f gb   (w > wb),  delta = |wb - w| / 2
+//   with g = n^-1/2, w = d^2 g^2 (cluster) and gb, wb (background).  One exp with a non-positive argument.
+struct BgGaussAcc {
+    double sum_min;        // sum min(w, wb)
+    LogProduct ly;         // sum log y_i
+    LogProduct lden;       // sum log(rho_i + f)
+    MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); }
+    MCD_HD void add(double d, double n, double db, double nb, double rho, double f) {
+        const double g = rsqrt_nr(n), gb = rsqrt_nr(nb);
+        const double w = (d * d) * (g * g), wb = (db * db) * (gb * gb);
+        const bool cluster_big = w <= wb;                 // cluster exponent -w/2 is the larger one
+        const double delta = cluster_big ? (wb - w) : (w - wb);
+        double u = -0.5 * delta;
+        u = u < -1.0e4 ? -1.0e4 : u;
+        int k;
+        const double er = exp_split(u, k);
+        const double e = ldexp_(er, k);                    // underflows to 0 harmlessly
+        const double a = rho * g, b = f * gb;
+        const double y = cluster_big ? fma_(b, e, a) : fma_(a, e, b);
+        ly.mul_any(y);
+        lden.mul(rho + f);
+        sum_min += cluster_big ? w : wb;
+    }
+    MCD_HD void rescale() { ly.rescale(); lden.rescale(); }
+    MCD_HD double finish(int64_t count) {
+        return fma_(-(double)count, kHalfLn2Pi, -0.5 * sum_min) + (ly.value() - lden.value());
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// One chunk of stars for one walker.  On the GPU `r` is wave-uniform (lane = walker), so every record
+// read below is a scalar load and the record values are SGPR operands of the vector ops.
+template <class T> struct WalkerConsts {
+    T vsys, s2, vx, vy, sac, cac, sdc, cdc, vb, sb2, fb;
+};
+
+template <class T, bool FREE>
+MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T& n) {
+    T s, c;
+    if (FREE) free_centre_geometry(r[2], r[3], r[4], r[5], w.sac, w.cac, w.sdc, w.cdc, s, c);
+    else { s = r[2]; c = r[3]; }
+    // v - (v_sys + v_maxx sin(theta) - v_maxy cos(theta))
+    d = fma_(-w.vx, s, fma_(w.vy, c, r[0] - w.vsys));
+    n = r[1] + w.s2;
+}
+
+template <int MODEL, bool FREE, class T, class A, bool FAST>
+MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w) {
+    constexpr int ND = record_doubles(MODEL, FREE);
+    double result;
+
+    if constexpr (MODEL == MODEL_CONST && FAST) {
+        // fraction-tree + log-product path (f64 only): 8 stars -> one division, one product factor
+        ConstAcc acc;
+        acc.init();
+        const int n8 = count >> 3;
+        for (int g = 0; g < n8; ++g, r += 8 * ND) {
+            double qq[8], nn[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                double d;
+                star_d_n<double, FREE>(r + j * ND, w, d, nn[j]);
+                qq[j] = d * d;
+            }
+            acc.add8(qq, nn);
+        }
+        for (int j = n8 * 8; j < count; ++j, r += ND) {
+            double d, n;
+            star_d_n<double, FREE>(r, w, d, n);
+            acc.add1(d * d, n);
+        }
+        result = acc.finish(count);
+    } else if constexpr (MODEL == MODEL_CONST) {
+        // plain path: one log and one division per term (runner.py:269-270 keeps two sums as well)
+        A sum_log = 0, sum_q = 0;
+#pragma unroll 4
+        for (int j = 0; j < count; ++j, r += ND) {
+            T d, n;
+            star_d_n<T, FREE>(r, w, d, n);
+            sum_log += (A)log_(n);
+            sum_q += (A)(d * d / n);
+        }
+        result = -0.5 * ((double)count * kLn2Pi + (double)sum_log + (double)sum_q);
+    } else if constexpr (MODEL == MODEL_BGFIXED && FAST) {
+        constexpr int XB = FREE ? 6 : 4;
+        BgFixedAcc acc;
+        acc.init();
+        const int n4 = count >> 2;
+        for (int g = 0; g < n4; ++g, r += 4 * ND) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double* rr = r + j * ND;
+                double d, n;
+                star_d_n<double, FREE>(rr, w, d, n);
+                acc.add(d, n, rr[XB], rr[XB + 1], rr[XB + 2], rr[XB + 3]);
+            }
+            acc.rescale();
+        }
+        for (int j = n4 * 4; j < count; ++j, r += ND) {
+            double d, n;
+            star_d_n<double, FREE>(r, w, d, n);
+            acc.add(d, n, r[XB], r[XB + 1], r[XB + 2], r[XB + 3]);
+        }
+        result = acc.finish();
+    } else if constexpr (MODEL == MODEL_BGGAUSS && FAST) {
+        constexpr int XB = FREE ? 6 : 4;
+        BgGaussAcc acc;
+        acc.init();
+        const int n4 = count >> 2;
+        for (int g = 0; g < n4; ++g, r += 4 * ND) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double* rr = r + j * ND;
+                double d, n;
+                star_d_n<double, FREE>(rr, w, d, n);
+                acc.add(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb);
+            }
+            acc.rescale();
+        }
+        for (int j = n4 * 4; j < count; ++j, r += ND) {
+            double d, n;
+            star_d_n<double, FREE>(r, w, d, n);
+            acc.add(d, n, r[0] - w.vb, r[1] + w.sb2, r[XB], w.fb);
+            acc.rescale();
+        }
+        result = acc.finish(count);
+    } else {
+        constexpr int XB = FREE ? 6 : 4;
+        A sum = 0;
+#pragma unroll 2
+        for (int j = 0; j < count; ++j, r += ND) {
+            T d, n;
+            star_d_n<T, FREE>(r, w, d, n);
+            const T m = gauss_lnl(d, n);
+            T b, p;
+            if (MODEL == MODEL_BGFIXED) {
+                b = r[XB];
+                p = r[XB + 1];
+            } else {
+                const T nb = r[1] + w.sb2;                       // constant.py:333
+                const T db = r[0] - w.vb;
+                b = gauss_lnl(db, nb);                           // constant.py:334-336
+                const T rho = r[XB];
+                p = rho / (rho + w.fb);                          // constant.py:339
+            }
+            sum += (A)mixture_lnl(m, b, p);                      // runner.py:282-284, constant.py:320-323
+        }
+        result = (double)sum;
+    }
+    return result;
+}
+
+}  // namespace mcd
