@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the per-walker log-likelihood hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: the log-likelihood of all 256 walkers over every
+star of the catalogue (``mcd_loglike_enqueue``: main kernel + fixed-order reduction [+ one RCCL
+all-reduce of 256 doubles when N > 1]).  Default workload = the configuration BASELINE.json's metric
+is quoted on (C3 of SURVEY.md section 8): 1e6 synthetic stars per GPU x 256 walkers, rotation +
+dispersion + fixed single-Gaussian background mixture, float64.  Star records and the walker table are
+resident in HBM before the timed region.  For N > 1 every rank holds its own 1e6-star shard (weak
+scaling) and the per-walker partial sums are all-reduced over xGMI.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip table)
+F64_VALU_PEAK_GOPS = 256 * 4 * 16 * 2.4    # lane-ops/ns: 256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2.4 GHz
+
+WORKLOADS = {
+    # name: (description, stars per GPU, walkers, model, algorithmic bytes per term, config number)
+    "c2": ("C2: 1e5 synthetic stars x 256 walkers, rotation+dispersion, fixed centre", 100000, 256, "const", 32, 2),
+    "c3": ("C3: 1e6 synthetic stars x 256 walkers, rotation+dispersion + fixed single-Gaussian background "
+           "mixture (ConstantFit + background.Gaussian), fixed centre", 1000000, 256, "bgfixed", 48, 3),
+    "c3gb": ("C3-GB: 1e6 synthetic stars x 256 walkers, ConstantFitGB (per-walker Gaussian background)", 1000000, 256,
+             "bggauss", 40, 3),
+    "c3const": ("1e6 synthetic stars x 256 walkers, rotation+dispersion without background", 1000000, 256, "const",
+                32, 3),
+    "c4": ("C4: 1e7 synthetic stars sharded over the GPUs (strong scaling), rotation+dispersion", 10000000, 256,
+           "const", 32, 4),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--stars", type=int, default=None, help="stars per GPU (override)")
+    ap.add_argument("--walkers", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
+    return ap.parse_args()
+
+
+def build_catalog(native, ctx, synthetic, oracle, cat, model):
+    centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
+    if model == "const":
+        return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST, centre=centre)
+    if model == "bgfixed":
+        # background/gaussian.py:23-28 evaluated once on the host (one-off precompute)
+        from mcmc_dynamics_amd.background import Gaussian
+        lnbg = Gaussian(synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])(cat["v"], cat["verr"])
+        return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST_BGFIXED,
+                              centre=centre, lnlike_bg=lnbg, pmember=cat["pmember"])
+    return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST_BGGAUSS,
+                          centre=centre, density=cat["density"])
+
+
+def cpu_baseline(cat, pos, model, budget_s):
+    """The oracle's faithful op-for-op NumPy restatement (one walker per call, as the reference's
+    ``Runner.lnprob``), timed on one host core over a bounded number of walkers."""
+    from oracle import lnprob_numpy as oracle
+    from mcmc_dynamics_amd import synthetic
+    centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
+    lnbg = None
+    if model == "bgfixed":
+        lnbg = oracle.gaussian_background(cat["v"], cat["verr"], synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])
+
+    def one(row):
+        if model == "bggauss":
+            return oracle.faithful_constant_gb_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
+                                                      row[4], row[5], row[6])
+        return oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
+                                               lnlike_background=lnbg, pmember=cat.get("pmember") if lnbg is not None else None)
+
+    one(pos[0])                                   # warm the allocator / caches
+    n, t0 = 0, time.perf_counter()
+    vals = []
+    while n < len(pos):
+        vals.append(one(pos[n]))
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    n_stars = len(cat["v"])
+    return {"value": n_stars * n / dt, "unit": "terms/s", "cores": 1, "kind": "port",
+            "sample": "{0} walkers x {1} stars, one walker per call, NumPy {2} (oracle/lnprob_numpy.py faithful path), "
+                      "{3:.1f} s".format(n, n_stars, np.__version__, dt)}, np.array(vals)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit("WORLD_SIZE={0} does not match --gpus {1}".format(world, args.gpus))
+
+    from mcmc_dynamics_amd import _native as native, synthetic
+    desc, n_stars, n_walkers, model, bytes_per_term, config = WORKLOADS[args.workload]
+    strong = args.workload == "c4"
+    if args.stars is not None:
+        n_stars = args.stars
+    if args.walkers is not None:
+        n_walkers = args.walkers
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist           # host-side rendezvous only (gloo); the data path is RCCL in the library
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        uid = [native.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx = native.Context(rank=rank, n_ranks=world, unique_id=uid[0], device=local_rank)
+    else:
+        ctx = native.Context(n_devices=1, device_ids=[local_rank])
+
+    # ---- synthetic catalogue shard of this rank; identical walkers on every rank
+    if strong:
+        full = synthetic.make_catalog(n_stars, config=config, background=(model != "const"))
+        lo, hi = n_stars * rank // world, n_stars * (rank + 1) // world
+        cat = {k: (v[lo:hi] if isinstance(v, np.ndarray) else v) for k, v in full.items()}
+        del full
+        total_stars = n_stars
+    else:
+        cat = synthetic.make_catalog(n_stars, config=config, seed=synthetic.CATALOG_SEED_BASE + config + 1000 * rank,
+                                     background=(model != "const"))
+        total_stars = n_stars * world
+    truth = cat["truth"]
+    if dist is not None and not strong:              # walkers are drawn around rank 0's truth everywhere
+        box = [truth if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        truth = box[0]
+    names = ["v_sys", "sigma_max", "v_maxx", "v_maxy"] + (["v_back", "sigma_back", "f_back"] if model == "bggauss" else [])
+    pos = synthetic.make_walkers(n_walkers, names, truth, config=config)
+
+    gpu_cat = build_catalog(native, ctx, synthetic, None, cat, model)
+    gpu_cat.set_option("timing", 2)
+    gpu_cat.upload_params(pos)
+
+    def barrier():
+        gpu_cat.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        gpu_cat.enqueue()
+    barrier()
+    gpu_cat.timing_collect()                         # drop warm-up launches
+
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gpu_cat.enqueue()
+    gpu_cat.sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    kernel_ms_total, n_launch = gpu_cat.timing_collect()
+    result = gpu_cat.fetch()
+    info = gpu_cat.launch_info()
+
+    # blocking C-ABI call (host params in, host results out) for the PCIe/sync-inclusive rate
+    t1 = time.perf_counter()
+    n_sync = max(5, min(50, args.steps))
+    for _ in range(n_sync):
+        gpu_cat.loglike(pos)
+    sync_call = (time.perf_counter() - t1) / n_sync
+    gpu_cat.timing_collect()
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    terms_per_step = float(total_stars) * n_walkers
+    value = terms_per_step * args.steps / elapsed
+    kernel_s = kernel_ms_total * 1e-3 / max(1, n_launch)
+    local_terms = float(len(cat["v"])) * n_walkers
+    achieved = local_terms * bytes_per_term / kernel_s / 1e9
+
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(args.workload)
+    except Exception:
+        pass
+
+    out = {
+        "metric": "star-walker log-L terms/sec", "value": value, "unit": "terms/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "stars_per_gpu": len(cat["v"]), "stars_total": total_stars, "walkers": n_walkers,
+                   "likelihood": model, "parallelism": "stars sharded over {0} rank(s); RCCL all-reduce of {1} doubles per step"
+                   .format(world, n_walkers) if world > 1 else "1 GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "algorithmic_bytes_per_term": bytes_per_term, "kernel_us": kernel_s * 1e6,
+                     "kernel": "mcd::loglike_kernel", "walker_tile": info["walker_tile"],
+                     "compulsory_bytes_per_launch": len(cat["v"]) * info["record_bytes"],
+                     "note": "streaming-model bytes (each walker's sum reads every star record once, SURVEY 8(d)); "
+                             "the kernel reuses one scalar record load for 64 walkers, so frac > 1 means register "
+                             "reuse and the binding resource is f64 VALU issue, not HBM"},
+        "hbm_algorithmic_GBps": value * bytes_per_term / 1e9,
+        "hbm_roofline_frac": value * bytes_per_term / 1e9 / HBM_PEAK_GBPS / world,
+        "sync_call_terms_per_s": local_terms * world / sync_call,
+        "sync_call_us": sync_call * 1e6,
+        "launch": info,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        base, vals = cpu_baseline(cat, pos, model, args.cpu_seconds)
+        out["cpu_baseline"] = base
+        err = np.max(np.abs(result[:len(vals)] - vals) / np.abs(vals))
+        out["gpu_vs_cpu_port_max_rel_err"] = float(err)
+        out["speedup_vs_cpu_1core"] = value / base["value"]
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

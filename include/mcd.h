@@ -151,12 +151,16 @@ int mcd_abi_version(void);
 double mcd_last_kernel_ms(const mcd_catalog* cat);
 double mcd_last_device_ms(const mcd_catalog* cat);
 /* Tuning / measurement switches, per catalogue.  Keys:
- *   "timing"        1: record HIP events around every enqueue (default 0)
+ *   "timing"        1: record HIP events around every enqueue (default 0); 2: additionally keep one
+ *                      event pair per main-kernel launch for mcd_timing_collect
  *   "fast_path"     0: always use the plain per-term log/divide kernels (default 1: the fraction-tree /
  *                      log-product kernel is used whenever the per-call range guard allows it)
  *   "target_waves"  number of waves the chunking aims for per device (default 8192)
  * Returns MCD_ERR_INVALID for an unknown key. */
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value);
+/* With "timing" = 2: waits for the device, returns the summed HIP-event duration (ms) of all main-kernel
+ * launches on device 0 of this process since the last collect / option change and their number. */
+int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_launches);
 /* Launch geometry of the main kernel for the last call: workgroups, walker tile (walkers that
  * reuse one star record load), chunks per parameter set, bytes per star record. */
 int mcd_last_launch_info(const mcd_catalog* cat, int64_t* n_workgroups, int32_t* walker_tile,

@@ -4,3 +4,7 @@ Python host code in the shape of the reference's ``mcmc_dynamics`` package, call
 gfx950 HIP kernels through the ctypes C-ABI of ``include/mcd.h``.  No CPU fallback exists.
 """
 __version__ = "0.1.0"
+
+from .parameter import Parameter, Parameters  # noqa: E402,F401
+from .utils.data_reader import DataReader  # noqa: E402,F401
+from .background import Gaussian, SingleStars  # noqa: E402,F401

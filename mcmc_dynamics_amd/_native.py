@@ -45,6 +45,7 @@ SYMBOLS = {
     "mcd_abi_version": (ctypes.c_int, []),
     "mcd_last_kernel_ms": (ctypes.c_double, [ctypes.c_void_p]),
     "mcd_last_device_ms": (ctypes.c_double, [ctypes.c_void_p]),
+    "mcd_timing_collect": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_int64_p]),
     "mcd_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "mcd_last_launch_info": (ctypes.c_int, [ctypes.c_void_p, _c_int64_p, ctypes.POINTER(ctypes.c_int32), _c_int64_p,
                                             ctypes.POINTER(ctypes.c_int32)]),
@@ -287,6 +288,13 @@ class Catalog(object):
     @property
     def last_device_ms(self):
         return self.lib.mcd_last_device_ms(self.handle)
+
+    def timing_collect(self):
+        """(summed main-kernel milliseconds, number of launches) since the last collect ("timing" = 2)."""
+        total, n = ctypes.c_double(), ctypes.c_int64()
+        _check(self.lib, self.lib.mcd_timing_collect(self.handle, ctypes.byref(total), ctypes.byref(n)),
+               "mcd_timing_collect")
+        return total.value, n.value
 
     def launch_info(self):
         wg, ch = ctypes.c_int64(), ctypes.c_int64()

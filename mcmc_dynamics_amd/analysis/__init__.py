@@ -1,0 +1,3 @@
+from .runner import Runner  # noqa: F401
+from .constant import ConstantFit, ConstantFitGB  # noqa: F401
+from .binned import BinnedConstantFit  # noqa: F401

@@ -1,0 +1,365 @@
+"""``Runner``: posterior API and MCMC driver, GPU-backed.
+
+Mirror of the reference's ``mcmc_dynamics/analysis/runner.py`` for the hot path: the method names,
+arguments and error behaviour of ``lnprior`` / ``lnlike`` / ``lnprob`` / ``fetch_parameter_values`` /
+``get_initials`` / ``__call__`` are kept (runner.py:143-443) so that emcee drives the outer loop
+unchanged, and a batched entry ``lnprob_batch((W, P)) -> (W,)`` is added, which is what the sampler
+is handed (``vectorize=True``).  The per-star arithmetic of ``_calculate_lnlike`` (runner.py:240-286)
+does not exist on the host: it runs in ``libmcd_hip.so`` on the star catalogue pinned in HBM.
+
+Differences that follow from dropping astropy: values are plain floats in the unit recorded in each
+``Parameter`` (the reference returns ``Quantity`` objects); ``lnprob`` returns a Python float.
+"""
+import logging
+import pickle
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _native, units
+from ..background import Gaussian, SingleStars
+from ..parameter import Parameters
+from ..utils.data_reader import DataReader
+from ..utils.results import ResultsTable
+
+logger = logging.getLogger(__name__)
+
+
+class Runner(object):
+    """Parent of the analysis classes.  Sub-classes name the observables and model parameters they
+    need (``OBSERVABLES``, ``MODEL_PARAMETERS``) and implement ``_lnlike_batch``."""
+
+    MODEL_PARAMETERS = []
+    OBSERVABLES = {"v": "km/s", "verr": "km/s"}
+    parameters_file = None
+
+    def __init__(self, data, parameters, seed=123, background=None, context=None, precision="f64", **kwargs):
+        """
+        Parameters
+        ----------
+        data : DataReader
+            The observed data.
+        parameters : Parameters
+            The model parameters.
+        seed : int, optional
+            Seed of the global NumPy random number generator (runner.py:59).
+        background : Gaussian or SingleStars, optional
+            Fixed background population; needs a ``pmember`` column in the data (runner.py:96-103).
+        context : _native.Context, optional
+            GPU context (devices / rank).  Default: one process-wide context on device 0.
+        precision : {'f64', 'f32', 'f32acc64'}
+            Arithmetic of the kernels; 'f64' is the parity mode.
+        """
+        assert not kwargs, "Unknown keyword arguments provided: {0}".format(kwargs)      # runner.py:56
+
+        np.random.seed(seed)                                                              # runner.py:59
+
+        assert isinstance(data, DataReader), "'data' must be instance of {0}".format(DataReader.__module__)
+        self.data = data
+
+        if "ra" in self.OBSERVABLES or "dec" in self.OBSERVABLES:
+            if not data.has_coordinates:
+                raise IOError("Missing WCS coordinates of observed data.")                # runner.py:70-72
+
+        for required, unit in self.OBSERVABLES.items():
+            assert required in data.data.columns, "Input data missing required column <{0}>".format(required)
+            if unit is not None and data.data.unit(required) is None:
+                logger.warning("Missing units for <%s> values. Assuming %s.", required, unit)
+            setattr(self, required, data.column(required, unit))
+
+        assert isinstance(parameters, Parameters), "'parameters' must be instance of {0}".format(Parameters.__module__)
+        self.parameters = parameters
+
+        missing = set(self.MODEL_PARAMETERS).difference(self.parameters)
+        if missing:
+            raise IOError("Missing required parameter(s): '{0}'".format(missing))          # runner.py:87-89
+        unused = set(self.parameters).difference(self.MODEL_PARAMETERS)
+        if unused:
+            logger.warning("Superfluous parameter(s) provided: '%s'", unused)
+
+        self.background = background
+        if self.background:
+            assert isinstance(background, (SingleStars, Gaussian)), \
+                "'background' must be an instance of a Background class."
+            if "pmember" not in self.data.data.columns:
+                logger.error("Inclusion of background population requires prior probabilities for membership.")
+            self.lnlike_background = np.asarray(self.background(self.v, self.verr), dtype=np.float64)
+            self.pmember = data.column("pmember")
+        else:
+            self.lnlike_background = None
+            self.pmember = None
+
+        self._context = context
+        self._precision = precision
+        self._catalog = None
+        self._catalog_key = None
+
+    # ------------------------------------------------------------------ bookkeeping
+    @classmethod
+    def default_parameters(cls):
+        if cls.parameters_file is None:
+            raise NotImplementedError
+        return Parameters().load(cls.parameters_file)
+
+    @property
+    def n_data(self):
+        return self.data.sample_size
+
+    @property
+    def fitted_parameters(self):
+        return [p for p in self.parameters if not self.parameters[p].fixed]
+
+    @property
+    def n_fitted_parameters(self):
+        return len(self.fitted_parameters)
+
+    @property
+    def units(self):
+        return {p: self.parameters[p].unit for p in self.parameters}
+
+    @property
+    def labels(self):
+        return [par.label for par in self.parameters.values() if not par.fixed]
+
+    @property
+    def context(self):
+        if self._context is None:
+            self._context = _native.default_context()
+        return self._context
+
+    # ------------------------------------------------------------------ single-walker API (reference names)
+    def fetch_parameter_values(self, values):
+        """Dictionary with one value per model parameter, fixed or not (runner.py:143-180).  As in the
+        reference, the values are also written back into ``self.parameters``."""
+        values = np.asarray(values, dtype=np.float64).reshape(-1)
+        resolved = self.parameters.resolve_batch(values[None, :])
+        current = OrderedDict((name, float(col[0])) for name, col in resolved.items())
+        for name, val in current.items():
+            if self.parameters[name].expr is None:
+                self.parameters[name].value = val                                          # runner.py:176
+        return current
+
+    def lnprior(self, values, parameters_to_ignore=None):
+        """0 when every parameter lies inside its inclusive bounds (plus optional ``lnprior``
+        expressions), -inf otherwise (runner.py:182-217)."""
+        values = np.asarray(values, dtype=np.float64).reshape(-1)
+        lnlike = 0
+        for name, value in self.fetch_parameter_values(values).items():
+            lnlike += self.parameters[name].evaluate_lnprior(value)
+            if not np.isfinite(lnlike):
+                return -np.inf
+        return lnlike
+
+    def lnlike(self, values):
+        """Log-likelihood of one parameter vector, without priors (place-holder in the reference,
+        runner.py:219-238; sub-classes evaluate it on the GPU)."""
+        values = np.asarray(values, dtype=np.float64).reshape(1, -1)
+        self.fetch_parameter_values(values[0])
+        return float(self.lnlike_batch(values)[0])
+
+    def lnprob(self, values):
+        """Log-posterior of one parameter vector (runner.py:288-306): the likelihood is not evaluated
+        when the prior is not finite."""
+        lp = self.lnprior(values)
+        if not np.isfinite(lp):
+            return -np.inf
+        return self.lnlike(values) + lp
+
+    # ------------------------------------------------------------------ batched API (new)
+    def lnprior_batch(self, values):
+        return self.parameters.lnprior_batch(self.parameters.resolve_batch(values))
+
+    def lnlike_batch(self, values):
+        """(W, P) free-parameter vectors -> (W,) log-likelihoods, one kernel launch."""
+        resolved = self.parameters.resolve_batch(values)
+        return self._lnlike_batch(resolved)
+
+    def lnprob_batch(self, values):
+        """(W, P) -> (W,) log-posteriors.  Walkers outside the prior get -inf; their rows are replaced by
+        a valid row for the launch and masked afterwards (the reference skips the evaluation)."""
+        values = np.atleast_2d(np.asarray(values, dtype=np.float64))
+        resolved = self.parameters.resolve_batch(values)
+        lp = self.parameters.lnprior_batch(resolved)
+        ok = np.isfinite(lp)
+        out = np.full(values.shape[0], -np.inf)
+        if not ok.any():
+            return out
+        if not ok.all():
+            donor = int(np.flatnonzero(ok)[0])
+            resolved = OrderedDict((k, np.where(ok, col, col[donor])) for k, col in resolved.items())
+        ll = self._lnlike_batch(resolved)
+        out[ok] = ll[ok] + lp[ok]
+        return out
+
+    def _lnlike_batch(self, resolved):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ sampler driver
+    def get_initials(self, n_walkers):
+        """Initial positions from each free parameter's ``initials`` recipe (runner.py:308-330)."""
+        initials = np.zeros((n_walkers, self.n_fitted_parameters))
+        i = 0
+        for parameter in self.parameters.values():
+            if parameter.fixed:
+                continue
+            initials[:, i] = parameter.evaluate_initials(n_walkers)
+            i += 1
+        return initials
+
+    def _make_sampler(self, n_walkers, seed=None):
+        try:
+            import emcee
+            return emcee.EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True)
+        except ImportError:
+            from ..sampler import EnsembleSampler
+            return EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True, seed=seed)
+
+    def __call__(self, n_walkers=100, n_steps=500, n_burn=100, n_threads=1, n_out=None, pos=None, lnprob0=None,
+                 plot=False, prefix="sampler", true_values=None, **kwargs):
+        """Run the MCMC (runner.py:332-443).  Same arguments as the reference; ``n_threads`` must be 1
+        because the likelihood of all walkers is one GPU launch (a process pool would fork after HIP
+        initialisation and hold W copies of the catalogue)."""
+        if kwargs:
+            if "filename" in kwargs or "plotfilename" in kwargs:
+                logger.warning("Parameters <filename> and <plotfilename> not used anymore. Use <prefix> instead.")
+        if n_threads != 1:
+            raise ValueError("n_threads > 1 is not supported by the GPU backend: walkers are batched on the device.")
+
+        fig = None
+        if plot:
+            import matplotlib.pyplot as plt
+            fig, _ = plt.subplots(self.n_fitted_parameters, 1, sharex="all", figsize=(8, 9))
+
+        if pos is not None:
+            pos = np.asarray(pos, dtype=np.float64)
+            assert pos.shape == (n_walkers, self.n_fitted_parameters), "Array with starting values has invalid shape."
+        else:
+            pos = self.get_initials(n_walkers=n_walkers)
+
+        lp0 = self.lnprior_batch(pos)
+        for i in range(n_walkers):
+            if not np.isfinite(lp0[i]):
+                raise ValueError("Invalid initial guesses for walker {0}: {1}={2}".format(
+                    i, self.fitted_parameters, pos[i]))                                      # runner.py:392-395
+
+        sampler = self._make_sampler(n_walkers)
+        logger.info("Running MCMC chain ...")
+        if n_out is not None:
+            logger.info("Iter. <log like>   " + "".join(" {0:12s}".format("<" + n + ">") for n in self.fitted_parameters))
+
+        state = None
+        while sampler.iteration < n_steps:
+            # runner.py:418-419.  One deliberate difference: the reference re-passes the caller's
+            # `lnprob0` on every chunk although the positions have moved; it is used for the first chunk only.
+            result = sampler.run_mcmc(pos, n_out if n_out is not None else n_steps, log_prob0=lnprob0,
+                                      rstate0=state, progress=False)
+            pos, lnp, state = tuple(result)[:3]
+            lnprob0 = None
+            if n_out is not None:
+                output = " {0:4d} {1:12.5e}".format(sampler.iteration, np.mean(lnp[:]))
+                output += "".join(" {0:12.5e}".format(np.mean(pos[:, i])) for i in range(self.n_fitted_parameters))
+                if sampler.iteration % n_out == 0:
+                    if prefix is not None:
+                        self.save_current_status(sampler, prefix=prefix)
+                    if plot:
+                        for ax in fig.axes:
+                            ax.cla()
+                        self.plot_chain(sampler.chain, true_values=true_values, figure=fig,
+                                        filename="{0}_chains.png".format(prefix) if prefix is not None else None)
+                logger.info(output)
+        return sampler
+
+    # ------------------------------------------------------------------ checkpoints (runner.py:445-519)
+    @staticmethod
+    def save_chain(sampler, filename="samplerchain.pkl"):
+        warnings.warn("Method Runner.save_chain() is deprecated. Use Runner.save_current_status() instead.",
+                      DeprecationWarning)
+        prefix = filename.split(".")[0]
+        if len(prefix) > 5 and prefix[-5:] == "chain":
+            prefix = prefix[:-5]
+        Runner.save_current_status(sampler, prefix=prefix)
+
+    @staticmethod
+    def save_current_status(sampler, prefix="sampler"):
+        """Pickle ``sampler.chain`` (W, steps, P) and ``sampler.lnprobability`` (W, steps) to
+        ``{prefix}_chain.pkl`` / ``{prefix}_lnprob.pkl`` -- the reference's on-disk format."""
+        with open("{0}_chain.pkl".format(prefix), "wb") as f:
+            pickle.dump(np.asarray(sampler.chain), f)
+        with open("{0}_lnprob.pkl".format(prefix), "wb") as f:
+            pickle.dump(np.asarray(sampler.lnprobability), f)
+
+    @staticmethod
+    def read_chain(filename="samplerchain.pkl"):
+        with open(filename, "rb") as f:
+            return pickle.load(f)
+
+    @staticmethod
+    def read_final_chain(filename="restart.plk"):
+        with open(filename, "rb") as f:
+            chain = pickle.load(f)
+        return chain[:, -1, :]
+
+    # ------------------------------------------------------------------ chain statistics (runner.py:521-660)
+    def convert_to_parameters(self, chain, n_burn):
+        """Chain (W, steps, P) -> dict name -> flat samples, including fixed and constrained parameters."""
+        chain = np.asarray(chain)
+        flat = chain[:, n_burn:, :].reshape(-1, chain.shape[2])
+        resolved = self.parameters.resolve_batch(flat)
+        return {name: np.array(col) for name, col in resolved.items()}
+
+    def compute_percentiles(self, chain, n_burn, pct=None):
+        if pct is None:
+            pct = [16, 50, 84]
+        samples = np.asarray(chain)[:, n_burn:, :].reshape((-1, self.n_fitted_parameters))
+        return np.percentile(samples, pct, axis=0)
+
+    def compute_bestfit_values(self, chain, n_burn):
+        """Median and upper / lower 1-sigma uncertainties per fitted parameter; the medians are also
+        written into ``self.parameters`` as in the reference (runner.py:649)."""
+        percentiles = self.compute_percentiles(chain, n_burn=n_burn, pct=[16, 50, 84])
+        results = ResultsTable()
+        i = 0
+        for name, parameter in self.parameters.items():
+            if parameter.fixed:
+                continue
+            parameter.value = percentiles[1, i]
+            results.add_column(name, percentiles[1, i], percentiles[2, i] - percentiles[1, i],
+                               percentiles[1, i] - percentiles[0, i], unit=parameter.unit)
+            i += 1
+        return results
+
+    def plot_chain(self, chain, filename="chains.png", true_values=None, figure=None, lnprob=None, plot_median=False):
+        """Trace plot of every fitted parameter (simplified form of runner.py:675-770)."""
+        import matplotlib.pyplot as plt
+        chain = np.asarray(chain)
+        if figure is None:
+            figure, _ = plt.subplots(self.n_fitted_parameters, 1, sharex="all", figsize=(8, 9))
+        for i, ax in enumerate(figure.axes[:self.n_fitted_parameters]):
+            ax.plot(chain[:, :, i].T, color="k", alpha=0.3, lw=0.6)
+            if plot_median:
+                ax.plot(np.median(chain[:, :, i], axis=0), color="C3", lw=1.5)
+            if true_values is not None:
+                ax.axhline(true_values[i], color="C0", lw=1.5)
+            ax.set_ylabel(self.labels[i])
+        if filename is not None:
+            figure.savefig(filename)
+        return figure
+
+    def sample_chain(self, chain, n_burn, n_samples):
+        """Random parameter draws from the post-burn-in chain (runner.py:820-850)."""
+        flat = np.asarray(chain)[:, n_burn:, :].reshape(-1, self.n_fitted_parameters)
+        idx = np.random.randint(flat.shape[0], size=n_samples)
+        return flat[idx]
+
+    # ------------------------------------------------------------------ device catalogue
+    def _canonical(self, resolved, name, unit):
+        """Resolved column of parameter ``name`` expressed in the kernel's canonical unit."""
+        f = units.conversion_factor(self.parameters[name].unit, unit) if self.parameters[name].unit else 1.0
+        return resolved[name] if f == 1.0 else resolved[name] * f
+
+    def close(self):
+        if self._catalog is not None:
+            self._catalog.close()
+            self._catalog = None
+            self._catalog_key = None

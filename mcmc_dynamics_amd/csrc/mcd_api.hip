@@ -112,6 +112,9 @@ struct Shard {
     void* records = nullptr;
     std::map<int64_t, WorkSet> work;   // keyed by walker count
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
+    // "timing" = 2: one (start, stop) event pair per main-kernel launch, summed by mcd_timing_collect
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ring;
+    size_t ring_used = 0;
 };
 
 }  // namespace
@@ -140,6 +143,7 @@ struct mcd_catalog {
     bool extras_ok = true;             // background columns inside the fast-path ranges
     // options
     bool timing = false;
+    bool timing_all = false;           // keep an event pair for every launch (measurement harness)
     bool allow_fast = true;
     int64_t target_waves = 8192;
     // state of the last evaluation
@@ -310,10 +314,22 @@ int enqueue(mcd_catalog* cat) {
         const DeviceSlot& slot = ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast};
+        hipEvent_t k0 = sh.ev_k0, k1 = sh.ev_k1;
+        if (cat->timing_all) {
+            if (sh.ring_used == sh.ring.size()) {
+                hipEvent_t a, b;
+                MCD_HIP(hipEventCreate(&a));
+                MCD_HIP(hipEventCreate(&b));
+                sh.ring.emplace_back(a, b);
+            }
+            k0 = sh.ring[sh.ring_used].first;
+            k1 = sh.ring[sh.ring_used].second;
+            ++sh.ring_used;
+        }
         if (cat->timing) MCD_HIP(hipEventRecord(sh.ev_begin, slot.stream));
-        if (cat->timing) MCD_HIP(hipEventRecord(sh.ev_k0, slot.stream));
+        if (cat->timing) MCD_HIP(hipEventRecord(k0, slot.stream));
         MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, W));
-        if (cat->timing) MCD_HIP(hipEventRecord(sh.ev_k1, slot.stream));
+        if (cat->timing) MCD_HIP(hipEventRecord(k1, slot.stream));
         MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, w.n_chunks,
                                    w.max_chunks_per_pset, W, w.d_out));
     }
@@ -356,7 +372,10 @@ int sync_all(mcd_catalog* cat) {
     if (cat->timing && cat->timing_pending) {
         Shard& sh = cat->shards[0];
         float k_ms = 0.f, d_ms = 0.f;
-        MCD_HIP(hipEventElapsedTime(&k_ms, sh.ev_k0, sh.ev_k1));
+        if (cat->timing_all && sh.ring_used > 0)
+            MCD_HIP(hipEventElapsedTime(&k_ms, sh.ring[sh.ring_used - 1].first, sh.ring[sh.ring_used - 1].second));
+        else
+            MCD_HIP(hipEventElapsedTime(&k_ms, sh.ev_k0, sh.ev_k1));
         MCD_HIP(hipEventElapsedTime(&d_ms, sh.ev_begin, sh.ev_end));
         cat->last_kernel_ms = k_ms;
         cat->last_device_ms = d_ms;
@@ -598,6 +617,7 @@ int mcd_catalog_destroy(mcd_catalog* cat) {
         if (sh.ev_k0) (void)hipEventDestroy(sh.ev_k0);
         if (sh.ev_k1) (void)hipEventDestroy(sh.ev_k1);
         if (sh.ev_end) (void)hipEventDestroy(sh.ev_end);
+        for (auto& pr : sh.ring) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     }
     delete cat;
     return MCD_OK;
@@ -653,7 +673,14 @@ int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* ou
 
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
     if (!cat || !key) return fail(MCD_ERR_INVALID, "mcd_set_option: null argument");
-    if (!std::strcmp(key, "timing")) { cat->timing = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "timing")) {
+        int rc = sync_all(cat);
+        if (rc != MCD_OK) return rc;
+        cat->timing = value != 0;
+        cat->timing_all = value == 2;
+        for (Shard& sh : cat->shards) sh.ring_used = 0;
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "fast_path")) { cat->allow_fast = value != 0; return MCD_OK; }
     if (!std::strcmp(key, "target_waves")) {
         if (value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");
@@ -669,6 +696,23 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     return fail(MCD_ERR_INVALID, std::string("unknown option: ") + key);
+}
+
+int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_launches) {
+    if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
+    int rc = sync_all(cat);
+    if (rc != MCD_OK) return rc;
+    Shard& sh = cat->shards[0];
+    double total = 0.0;
+    for (size_t i = 0; i < sh.ring_used; ++i) {
+        float ms = 0.f;
+        MCD_HIP(hipEventElapsedTime(&ms, sh.ring[i].first, sh.ring[i].second));
+        total += ms;
+    }
+    if (total_kernel_ms) *total_kernel_ms = total;
+    if (n_launches) *n_launches = (int64_t)sh.ring_used;
+    for (Shard& s2 : cat->shards) s2.ring_used = 0;
+    return MCD_OK;
 }
 
 double mcd_last_kernel_ms(const mcd_catalog* cat) { return cat ? cat->last_kernel_ms : -1.0; }

@@ -1,0 +1,124 @@
+"""Affine-invariant ensemble sampler (Goodman & Weare 2010 stretch move) with emcee's interface.
+
+The reference hands ``Runner.lnprob`` to ``emcee.EnsembleSampler`` (analysis/runner.py:403) and lets
+emcee drive the outer loop.  emcee is not installed in the target image, so ``Runner.__call__`` uses
+the real emcee when it can be imported and this class otherwise.  It implements the part of emcee 3's
+``EnsembleSampler`` that the reference touches -- ``run_mcmc``, ``chain``, ``lnprobability``,
+``iteration``, ``acceptance_fraction`` -- with emcee's default move: the ensemble is split in two
+random halves, each half is updated against the other (``z ~ g(z) \\propto 1/sqrt(z)`` on [1/a, a],
+``a = 2``), so one step costs two batched posterior calls of W/2 proposals each.
+
+``vectorize=True`` (the mode the GPU backend uses) passes a ``(n, ndim)`` array to ``log_prob_fn`` and
+expects ``(n,)`` back; otherwise the function is mapped over the rows (optionally with ``pool.map``).
+"""
+import numpy as np
+
+
+class EnsembleSampler(object):
+
+    def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, a=2.0, vectorize=False, seed=None):
+        if nwalkers < 2 * ndim:
+            raise ValueError("The number of walkers must be at least twice the dimension.")   # as emcee
+        if nwalkers % 2:
+            raise ValueError("The number of walkers must be even.")
+        self.nwalkers, self.ndim = int(nwalkers), int(ndim)
+        self.log_prob_fn = log_prob_fn
+        self.pool = pool
+        self.a = float(a)
+        self.vectorize = bool(vectorize)
+        self._random = np.random.RandomState(seed)
+        self.reset()
+
+    def reset(self):
+        self.iteration = 0
+        self._chain = np.empty((0, self.nwalkers, self.ndim))
+        self._lnprob = np.empty((0, self.nwalkers))
+        self._accepted = np.zeros(self.nwalkers)
+        self.n_calls = 0
+
+    # ------------------------------------------------------------------ emcee-compatible views
+    @property
+    def chain(self):
+        """(nwalkers, nsteps, ndim), the layout the reference pickles (runner.py:471-472)."""
+        return np.swapaxes(self._chain[:self.iteration], 0, 1)
+
+    @property
+    def lnprobability(self):
+        return np.swapaxes(self._lnprob[:self.iteration], 0, 1)
+
+    @property
+    def flatchain(self):
+        return self._chain[:self.iteration].reshape(-1, self.ndim)
+
+    @property
+    def acceptance_fraction(self):
+        return self._accepted / max(1, self.iteration)
+
+    def get_chain(self, discard=0, flat=False):
+        c = self._chain[discard:self.iteration]
+        return c.reshape(-1, self.ndim) if flat else c
+
+    def get_log_prob(self, discard=0, flat=False):
+        lp = self._lnprob[discard:self.iteration]
+        return lp.reshape(-1) if flat else lp
+
+    @property
+    def random_state(self):
+        return self._random.get_state()
+
+    # ------------------------------------------------------------------ posterior calls
+    def compute_log_prob(self, coords):
+        coords = np.asarray(coords, dtype=np.float64)
+        if np.any(np.isinf(coords)) or np.any(np.isnan(coords)):
+            raise ValueError("At least one parameter value was infinite or NaN")
+        if self.vectorize:
+            lp = np.asarray(self.log_prob_fn(coords), dtype=np.float64)
+        elif self.pool is not None:
+            lp = np.array([float(x) for x in self.pool.map(self.log_prob_fn, list(coords))], dtype=np.float64)
+        else:
+            lp = np.array([float(self.log_prob_fn(c)) for c in coords], dtype=np.float64)
+        self.n_calls += 1
+        if lp.shape != (coords.shape[0],):
+            raise ValueError("log_prob_fn returned shape {0} for {1} positions".format(lp.shape, coords.shape[0]))
+        if np.any(np.isnan(lp)):
+            raise ValueError("Probability function returned NaN")
+        return lp
+
+    # ------------------------------------------------------------------ sampling
+    def run_mcmc(self, initial_state, nsteps, log_prob0=None, rstate0=None, progress=False, store=True, **kwargs):
+        """Advance the ensemble by ``nsteps``.  Returns ``(pos, log_prob, random_state)``."""
+        pos = np.array(initial_state, dtype=np.float64)
+        if pos.shape != (self.nwalkers, self.ndim):
+            raise ValueError("incompatible input dimensions {0}".format(pos.shape))
+        if rstate0 is not None:
+            self._random.set_state(rstate0)
+        lnp = self.compute_log_prob(pos) if log_prob0 is None else np.array(log_prob0, dtype=np.float64)
+        if np.shape(lnp) != (self.nwalkers,):
+            raise ValueError("incompatible input dimensions for log_prob0")
+        if store:
+            grow = self.iteration + int(nsteps) - self._chain.shape[0]
+            if grow > 0:
+                self._chain = np.concatenate([self._chain, np.empty((grow, self.nwalkers, self.ndim))])
+                self._lnprob = np.concatenate([self._lnprob, np.empty((grow, self.nwalkers))])
+        half = self.nwalkers // 2
+        rnd = self._random
+        for _ in range(int(nsteps)):
+            order = rnd.permutation(self.nwalkers)
+            for first, second in ((order[:half], order[half:]), (order[half:], order[:half])):
+                s, c = pos[first], pos[second]
+                ns = len(first)
+                zz = ((self.a - 1.0) * rnd.rand(ns) + 1.0) ** 2.0 / self.a
+                partners = c[rnd.randint(len(second), size=ns)]
+                proposal = partners - (partners - s) * zz[:, None]
+                new_lnp = self.compute_log_prob(proposal)
+                lnpdiff = (self.ndim - 1.0) * np.log(zz) + new_lnp - lnp[first]
+                accept = np.log(rnd.rand(ns)) < lnpdiff
+                idx = first[accept]
+                pos[idx] = proposal[accept]
+                lnp[idx] = new_lnp[accept]
+                self._accepted[idx] += 1
+            if store:
+                self._chain[self.iteration] = pos
+                self._lnprob[self.iteration] = lnp
+            self.iteration += 1
+        return pos, lnp, self._random.get_state()

@@ -111,3 +111,146 @@ def test_abi_errors(native, ctx):
         native.Catalog(ctx, g["ra"], g["dec"], g["v"], g["verr"], model=native.MODEL_CONST_BGGAUSS, centre=None)
     empty = native.Catalog(ctx, [], [], [], [], model=native.MODEL_CONST, centre=(0.0, 0.0))
     assert np.array_equal(empty.loglike(g["values"]), np.zeros(len(g["values"])))
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes (the oracle would take minutes there)
+def _synthetic(n, config, background=False):
+    from mcmc_dynamics_amd import synthetic
+    c = synthetic.make_catalog(n, config=config, background=background)
+    return c, (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
+
+
+NAMES4 = ["v_sys", "sigma_max", "v_maxx", "v_maxy"]
+
+
+def test_full_size_c3_properties(native, ctx):
+    """1e6 stars x 256 walkers, background mixture: fast == plain path, shard sums == total, bitwise
+    reproducible, and a 16-walker x 1e5-star slice agrees with the oracle."""
+    from mcmc_dynamics_amd import synthetic
+    from oracle import lnprob_numpy as oracle
+    c, centre = _synthetic(1000000, 3, background=True)
+    pos = synthetic.make_walkers(256, NAMES4, c["truth"], config=3)
+    lnbg = oracle.gaussian_background(c["v"], c["verr"], 20.0, 40.0)
+
+    def make(sl, model=None):
+        return native.Catalog(ctx, c["ra"][sl], c["dec"][sl], c["v"][sl], c["verr"][sl],
+                              model=native.MODEL_CONST_BGFIXED, centre=centre, lnlike_bg=lnbg[sl], pmember=c["pmember"][sl])
+
+    full = make(slice(None))
+    a = full.loglike(pos)
+    b = full.loglike(pos)
+    assert np.array_equal(a, b)                                       # fixed reduction tree: bitwise stable
+    full.set_option("fast_path", 0)
+    assert rel_err(full.loglike(pos), a) < RTOL                        # both formulations, 2.56e8 terms
+    parts = sum(make(slice(lo, hi)).loglike(pos) for lo, hi in ((0, 333333), (333333, 700001), (700001, 1000000)))
+    assert rel_err(parts, a) < RTOL                                    # sharded sum == un-sharded (SURVEY 8(c) #5)
+    sl = slice(0, 100000)
+    sub = {k: v[sl] for k, v in c.items() if isinstance(v, np.ndarray)}
+    want = oracle.batched_constant_lnlike(sub, pos[:16], *centre, lnlike_background=lnbg[sl], pmember=sub["pmember"])
+    assert rel_err(make(sl).loglike(pos[:16]), want) < RTOL
+    full.upload_params(pos)                                            # device-resident pipeline == blocking call
+    full.set_option("fast_path", 1)
+    full.upload_params(pos)
+    full.enqueue()
+    full.enqueue()
+    assert np.array_equal(full.fetch(), a)
+
+
+def test_ragged_shapes(native, ctx):
+    """W not a multiple of the 64-lane walker tile, N not a multiple of the 8-star group, tiny N."""
+    from mcmc_dynamics_amd import synthetic
+    from oracle import lnprob_numpy as oracle
+    for n, w in ((1, 1), (7, 3), (63, 65), (1001, 130), (4097, 64)):
+        c, centre = _synthetic(n, 2)
+        pos = synthetic.make_walkers(w, NAMES4, c["truth"], config=2)
+        cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
+        want = oracle.batched_constant_lnlike(c, pos, *centre)
+        assert rel_err(cat.loglike(pos), want) < RTOL
+        cat.set_option("target_waves", 64)                             # long chunks: many 8-groups + tail
+        assert rel_err(cat.loglike(pos), want) < RTOL
+
+
+def test_physical_invariances(native, ctx):
+    """(2) pmember == 1 mixture == no-background; (3) rotating every position angle and theta_0 by the same
+    angle leaves lnL unchanged; f_back = 0 mixture == no-background."""
+    from mcmc_dynamics_amd import synthetic
+    c, centre = _synthetic(20000, 3, background=True)
+    pos = synthetic.make_walkers(64, NAMES4, c["truth"], config=3)
+    plain = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre).loglike(pos)
+    mix = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST_BGFIXED, centre=centre,
+                         lnlike_bg=np.full(20000, -7.0), pmember=np.ones(20000)).loglike(pos)
+    assert rel_err(mix, plain) < RTOL
+    pos7 = np.hstack([pos, np.tile([20.0, 40.0, 0.0], (64, 1))])
+    gb = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST_BGGAUSS, centre=centre,
+                        density=c["density"]).loglike(pos7)
+    assert rel_err(gb, plain) < RTOL
+    # rotate the sky about the centre by delta: (dx, dy) -> R(delta)(dx, dy), and (v_maxx, v_maxy) likewise
+    from oracle import lnprob_numpy as oracle
+    delta = 0.7
+    dx, dy = oracle.calc_xy_offset(c["ra"], c["dec"], *centre)
+    rx, ry = np.cos(delta) * dx - np.sin(delta) * dy, np.sin(delta) * dx + np.cos(delta) * dy
+    ra2, dec2 = synthetic.offsets_to_radec(rx, ry, *centre)
+    pos_rot = pos.copy()
+    pos_rot[:, 2] = np.cos(delta) * pos[:, 2] - np.sin(delta) * pos[:, 3]
+    pos_rot[:, 3] = np.sin(delta) * pos[:, 2] + np.cos(delta) * pos[:, 3]
+    rot = native.Catalog(ctx, ra2, dec2, c["v"], c["verr"], model=native.MODEL_CONST, centre=centre).loglike(pos_rot)
+    assert rel_err(rot, plain) < 1e-10                                   # inverse projection round trip ~1e-13 rad
+
+
+def test_out_of_range_inputs_take_the_plain_path(native, ctx):
+    """sigma = 0 with a zero-error star makes norm = 0: the range guard must route to the plain kernels,
+    which reproduce the reference's non-finite result instead of a wrong finite one."""
+    from mcmc_dynamics_amd import synthetic
+    c, centre = _synthetic(500, 2)
+    verr = c["verr"].copy()
+    verr[10] = 0.0
+    cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], verr, model=native.MODEL_CONST, centre=centre)
+    pos = synthetic.make_walkers(8, NAMES4, c["truth"], config=2)
+    assert np.all(np.isfinite(cat.loglike(pos)))
+    pos[3, 1] = 0.0
+    out = cat.loglike(pos)
+    assert not np.isfinite(out[3]) and np.all(np.isfinite(np.delete(out, 3)))
+    huge = pos.copy()
+    huge[:, 1] = 1e40                                                    # sigma^2 = 1e80 > 2^60: guard -> plain
+    from oracle import lnprob_numpy as oracle
+    cat2 = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
+    assert rel_err(cat2.loglike(huge), oracle.batched_constant_lnlike(c, huge, *centre)) < RTOL
+
+
+def test_precision_sweep_c5(native, ctx):
+    """float32 vs float64 on a radial-binned catalogue (C5): f32 terms + f64 accumulation <= 1e-6, pure f32
+    <= 2e-5 relative (SURVEY appendix measured 9.5e-9 / 1.8e-7 at 1e5 stars)."""
+    from mcmc_dynamics_amd import synthetic
+    from oracle import lnprob_numpy as oracle
+    c, centre = _synthetic(200000, 5)
+    dx, dy = oracle.calc_xy_offset(c["ra"], c["dec"], *centre)
+    bins = oracle.make_radial_bins(np.hypot(dx, dy), 1000, 0.05).astype(np.int64)
+    order = np.argsort(bins, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(bins))])
+    n_bins = len(offs) - 1
+    pos = synthetic.make_walkers(128, NAMES4, c["truth"], config=5)
+    params = np.broadcast_to(pos, (n_bins,) + pos.shape)
+    out = {}
+    for prec in ("f64", "f32acc64", "f32"):
+        cat = native.Catalog(ctx, c["ra"][order], c["dec"][order], c["v"][order], c["verr"][order],
+                             model=native.MODEL_CONST, centre=centre, bin_offsets=offs, precision=prec)
+        out[prec] = cat.loglike(params)
+        assert out[prec].shape == (n_bins, 128)
+    b0 = slice(offs[0], offs[1])
+    sub = {k: c[k][order][b0] for k in ("ra", "dec", "v", "verr")}
+    assert rel_err(out["f64"][0], oracle.batched_constant_lnlike(sub, pos, *centre)) < RTOL
+    assert rel_err(out["f32acc64"], out["f64"]) < 1e-6
+    assert rel_err(out["f32"], out["f64"]) < 2e-5
+
+
+def test_rank_mode_context_single_rank(native):
+    """One-process-per-GPU entry point with a world of one: no RCCL, same numbers."""
+    from mcmc_dynamics_amd import synthetic
+    c, centre = _synthetic(3000, 4)
+    pos = synthetic.make_walkers(64, NAMES4, c["truth"], config=4)
+    ctx1 = native.Context(rank=0, n_ranks=1, device=0)
+    a = native.Catalog(ctx1, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre).loglike(pos)
+    b = native.Catalog(native.default_context(), c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST,
+                       centre=centre).loglike(pos)
+    assert np.array_equal(a, b)

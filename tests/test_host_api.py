@@ -1,0 +1,250 @@
+"""Host logic (no GPU): Parameters / DataReader / backgrounds / Runner contract / sampler, and the
+C-ABI library's load-time contract (every symbol of include/mcd.h exported; no compute calls)."""
+import io
+import json
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, rel_err
+
+from mcmc_dynamics_amd import DataReader, Gaussian, Parameter, Parameters, SingleStars, _native, synthetic
+from mcmc_dynamics_amd.analysis import BinnedConstantFit, ConstantFit, ConstantFitGB, Runner
+from mcmc_dynamics_amd.sampler import EnsembleSampler
+
+# a parameter file in the reference's JSON layout (same schema as its config/constant_with_background.json)
+REFERENCE_LAYOUT_JSON = json.dumps({
+    "unique_symbols": {"rng_seed": 5},
+    "params": [
+        ["v_sys", None, "km/s", False, float("-inf"), float("inf"), "$v_{\\rm sys}$", "rng.normal(size=n)", None, None, None],
+        ["sigma_max", None, "km/s", False, 0.0, float("inf"), "$\\sigma$", "rng.lognormal(size=n)", None, None, None],
+        ["v_maxx", None, "km/s", False, float("-inf"), float("inf"), None, "rng.normal(size=n)", None, None, None],
+        ["v_maxy", None, "km/s", False, float("-inf"), float("inf"), None, None, None, None, "2*v_maxx"],
+        ["ra_center", 56.345, "deg", True, 0.0, 360.0, None, None, None, None, None],
+        ["dec_center", -26.675, "deg", True, -90.0, 90.0, None, None, None, None, None],
+        ["f_back", None, None, False, 0.0, 1.0, None, "rng.uniform(size=n)", "log(val + 1)", None, None],
+    ]})
+
+
+def small_reader(n=300, background=True):
+    c = synthetic.make_catalog(n, config=2, background=background)
+    return DataReader({k: c[k] for k in c if k != "truth"}), c
+
+
+# ------------------------------------------------------------------------------------------ native library
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mcd.h")).read()
+    declared = set(re.findall(r"\b(mcd_[a-z_0-9]+)\s*\(", header))
+    declared -= {"mcd_ctx", "mcd_catalog"}
+    assert len(declared) >= 20
+    lib = _native.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libmcd_hip.so does not export " + name
+        assert name in _native.SYMBOLS, "ctypes binding lacks " + name
+    assert lib.mcd_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    """Without a usable gfx950 device the product path must fail loudly, not compute on the host."""
+    lib = _native.load_library()
+    import ctypes
+    n = ctypes.c_int(0)
+    hip = ctypes.CDLL("libamdhip64.so")
+    if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    reader, c = small_reader()
+    cf = ConstantFit(reader)
+    cf.parameters["ra_center"].set(value=c["truth"]["ra_center"], fixed=True)
+    cf.parameters["dec_center"].set(value=c["truth"]["dec_center"], fixed=True)
+    with pytest.raises(_native.NativeError):
+        cf.lnprob(np.array([0.0, 10.0, 1.0, 1.0]))
+    with pytest.raises(_native.NativeError):
+        _native.load_library(os.path.join(ROOT, "does_not_exist.so"))
+    import mcmc_dynamics_amd
+    src = "".join(open(os.path.join(dp, f)).read() for dp, _, fs in os.walk(os.path.dirname(mcmc_dynamics_amd.__file__))
+                  for f in fs if f.endswith(".py"))
+    assert "oracle" not in src.replace("oracle/make_golden.py", ""), "the product package must not reference the oracle"
+
+
+# ------------------------------------------------------------------------------------------ Parameters
+def test_parameters_reference_json_layout_roundtrip():
+    pars = Parameters().load(io.StringIO(REFERENCE_LAYOUT_JSON))
+    assert list(pars) == ["v_sys", "sigma_max", "v_maxx", "v_maxy", "ra_center", "dec_center", "f_back"]
+    assert pars.free_names() == ["v_sys", "sigma_max", "v_maxx", "f_back"]        # expr => fixed
+    assert pars["sigma_max"].min == 0.0 and pars["f_back"].max == 1.0 and pars["v_sys"].unit == "km/s"
+    assert pars["f_back"].value == 0.5                     # midpoint of finite bounds (parameter.py:795-796)
+    again = Parameters().loads(pars.dumps())
+    assert [p.__getstate__() for p in again.values()] == [p.__getstate__() for p in pars.values()]
+    clone = pickle.loads(pickle.dumps(pars))
+    assert list(clone) == list(pars) and clone["v_maxy"].expr == "2*v_maxx"
+    draws = pars["v_sys"].evaluate_initials(7)
+    assert draws.shape == (7,)
+    assert np.allclose(Parameters().load(io.StringIO(REFERENCE_LAYOUT_JSON))["v_sys"].evaluate_initials(7), draws)
+
+
+def test_bounds_are_inclusive_and_checked_for_fixed_parameters():
+    pars = Parameters().load(io.StringIO(REFERENCE_LAYOUT_JSON))
+    p = pars["sigma_max"]
+    assert p.evaluate_lnprior(0.0) == 0 and p.evaluate_lnprior(-1e-300) == -np.inf
+    assert pars["f_back"].evaluate_lnprior(1.0) == pytest.approx(np.log(2.0))
+    assert pars["f_back"].evaluate_lnprior(1.0000001) == -np.inf
+    vals = np.array([[0.0, 0.0, 1.0, 0.0], [0.0, -1.0, 1.0, 0.5], [0.0, 2.0, 1.0, 1.0], [0.0, 2.0, 1.0, 1.5]])
+    res = pars.resolve_batch(vals)
+    assert np.array_equal(res["v_maxy"], 2.0 * vals[:, 2])          # constraint evaluated on arrays
+    lp = pars.lnprior_batch(res)
+    assert np.array_equal(np.isfinite(lp), [True, False, True, False])
+    assert lp[2] == pytest.approx(np.log(2.0))
+    pars["dec_center"].set(value=-26.0)
+    pars["dec_center"].max = -30.0                                   # a fixed value outside its bounds ...
+    assert not np.isfinite(pars.lnprior_batch(pars.resolve_batch(vals))).any()   # ... rejects everything (runner.py:207-214)
+    with pytest.raises(ValueError):
+        Parameter("x", min=1.0, max=1.0)
+    with pytest.raises(KeyError):
+        Parameters().add("not a name", value=1.0)
+
+
+def test_unit_handling():
+    p = Parameter("a", value=30.0, unit="arcsec", min=0.0)
+
+    class Q(object):                                       # duck-typed astropy Quantity
+        def __init__(self, value, unit):
+            self.value, self.unit = value, unit
+
+    p.set(value=Q(1.0, "arcmin"))
+    assert p.value == pytest.approx(60.0)
+    assert p.evaluate_lnprior(Q(-1.0, "arcmin")) == -np.inf
+    with pytest.raises(IOError):
+        p.set(value=Q(1.0, "km/s"))
+
+
+# ------------------------------------------------------------------------------------------ data + backgrounds
+def test_datareader_bins_match_reference():
+    g = load_golden("radial_bins")
+    reader = DataReader({"ra": g["ra"], "dec": g["dec"], "v": g["v"], "verr": g["verr"]})
+    r = reader.compute_distances(float(g["ra_center"]), float(g["dec_center"]))
+    assert rel_err(r, g["r_arcmin"]) < 1e-12
+    reader.make_radial_bins(float(g["ra_center"]), float(g["dec_center"]), nstars=200, dlogr=0.05)
+    assert reader.data["bin"].dtype == np.int16
+    assert np.array_equal(reader.data["bin"], g["bins_n200_d005"])
+    reader.make_radial_bins(float(g["ra_center"]), float(g["dec_center"]), nstars=50, dlogr=0.1)
+    assert np.array_equal(reader.data["bin"], g["bins_n50_d01"])
+    sub = reader.fetch_radial_bin(3)
+    assert sub.sample_size == int(np.sum(g["bins_n50_d01"] == 3)) and set(sub.data.columns) >= {"ra", "v", "bin"}
+    assert reader.fetch_radial_bin(99) is None
+    srt, offs = reader.sorted_by_bin()
+    assert offs[0] == 0 and offs[-1] == reader.sample_size and np.all(np.diff(srt.data["bin"]) >= 0)
+
+
+def test_background_models():
+    g = load_golden("constant_bg_gaussian_fixed")
+    bg = Gaussian(mean=float(g["bg_mean"]), sigma=float(g["bg_sigma"]))
+    assert np.max(np.abs(bg(g["v"], g["verr"]) - g["lnlike_background"])) < 1e-12
+    v, verr = g["v"][:50], g["verr"][:50]
+    comp = np.array([-30.0, 10.0, 55.0, 80.0])
+    ss = SingleStars(comp)
+    direct = np.log(np.mean(np.exp(-0.5 * (comp[:, None] - v[None, :]) ** 2 / verr ** 2) /
+                            np.sqrt(2 * np.pi * verr ** 2), axis=0))
+    assert np.max(np.abs(ss(v, verr) - direct)) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------ Runner contract
+def test_runner_constructor_contract():
+    reader, c = small_reader()
+    with pytest.raises(AssertionError):
+        ConstantFit(reader, initials=3)                       # unknown kwargs (runner.py:56)
+    with pytest.raises(AssertionError):
+        ConstantFit({"v": [1.0]})                             # data must be a DataReader
+    with pytest.raises(IOError):
+        ConstantFit(DataReader({"v": c["v"], "verr": c["verr"]}))       # missing coordinates (runner.py:70-72)
+    with pytest.raises(AssertionError):
+        ConstantFitGB(DataReader({k: c[k] for k in ("ra", "dec", "v", "verr")}))   # missing density column
+    pars = ConstantFit.default_parameters()
+    del pars["v_maxy"]
+    with pytest.raises(IOError):
+        ConstantFit(reader, parameters=pars)                  # missing model parameter (runner.py:87-89)
+    with pytest.raises(AssertionError):
+        ConstantFit(reader, background="gaussian")            # must be a background instance
+    with pytest.raises(KeyError):
+        ConstantFit(DataReader({k: c[k] for k in ("ra", "dec", "v", "verr")}), background=Gaussian(20.0, 40.0))
+    cf = ConstantFit(reader)
+    assert cf.fitted_parameters == ["v_sys", "sigma_max", "v_maxx", "v_maxy", "ra_center", "dec_center"]
+    cf.parameters["ra_center"].set(value=56.345, fixed=True)
+    cf.parameters["dec_center"].set(value=-26.675, fixed=True)
+    assert cf.fitted_parameters == ["v_sys", "sigma_max", "v_maxx", "v_maxy"] and cf.n_fitted_parameters == 4
+    assert ConstantFitGB(reader).fitted_parameters[-3:] == ["v_back", "sigma_back", "f_back"]
+    assert cf.lnprior([0.0, 0.0, 1.0, 1.0]) == 0 and cf.lnprior([0.0, -0.1, 1.0, 1.0]) == -np.inf
+    assert cf.lnprob([0.0, -0.1, 1.0, 1.0]) == -np.inf       # prior failure: likelihood never evaluated (no GPU needed)
+    assert cf.fetch_parameter_values([1.0, 2.0, 3.0, 4.0])["ra_center"] == 56.345
+    with pytest.raises(AssertionError):
+        cf.fetch_parameter_values([1.0, 2.0, 3.0])           # 'Not all parameters used.' (runner.py:178)
+    init = cf.get_initials(16)
+    assert init.shape == (16, 4) and np.all(init[:, 1] > 0)
+    with pytest.raises(ValueError):
+        cf(n_walkers=8, n_steps=2, n_threads=4)
+    bad = init.copy()
+    bad[3, 1] = -1.0
+    with pytest.raises(ValueError, match="Invalid initial guesses for walker 3"):
+        cf(n_walkers=16, n_steps=1, pos=bad)
+    assert np.array_equal(cf.lnprob_batch(np.tile([0.0, -1.0, 0.0, 0.0], (4, 1))), np.full(4, -np.inf))
+    v_los = cf.rotation_model(1.0, 2.0, -1.0, 56.345, -26.675)
+    assert v_los.shape == (reader.sample_size,) and np.all(cf.dispersion_model(7.0) == 7.0)
+    with pytest.raises(IOError):
+        BinnedConstantFit(reader)                             # needs the bin column
+
+
+def test_chain_statistics():
+    reader, _ = small_reader()
+    cf = ConstantFit(reader)
+    cf.parameters["ra_center"].set(value=56.345, fixed=True)
+    cf.parameters["dec_center"].set(value=-26.675, fixed=True)
+    rng = np.random.default_rng(0)
+    chain = rng.normal([1.0, 10.0, 3.0, 4.0], [0.1, 0.5, 0.2, 0.2], size=(20, 60, 4))
+    best = cf.compute_bestfit_values(chain, n_burn=10)
+    assert best.loc["median"]["sigma_max"] == pytest.approx(10.0, abs=0.1)
+    assert best.loc["uperr"]["v_sys"] == pytest.approx(0.1, rel=0.3)
+    tv = cf.compute_theta_vmax(chain, n_burn=10)
+    assert tv.loc["median"]["v_max"] == pytest.approx(5.0, abs=0.1)
+    assert tv.loc["median"]["theta_0"] == pytest.approx(np.arctan2(4.0, 3.0), abs=0.02)
+    pars = cf.convert_to_parameters(chain, n_burn=10)
+    assert pars["ra_center"].shape == (20 * 50,) and np.all(pars["ra_center"] == 56.345)
+
+
+def test_checkpoint_format(tmp_path):
+    """{prefix}_chain.pkl holds (W, steps, P), {prefix}_lnprob.pkl holds (W, steps) (runner.py:458-477);
+    read_final_chain returns chain[:, -1, :] for restarts (runner.py:499-519)."""
+
+    def log_prob(x):
+        return -0.5 * np.sum(x ** 2, axis=1)
+
+    s = EnsembleSampler(8, 2, log_prob, vectorize=True, seed=1)
+    s.run_mcmc(np.random.default_rng(0).normal(size=(8, 2)), 5)
+    prefix = str(tmp_path / "run")
+    Runner.save_current_status(s, prefix=prefix)
+    chain = Runner.read_chain(prefix + "_chain.pkl")
+    assert chain.shape == (8, 5, 2) and Runner.read_chain(prefix + "_lnprob.pkl").shape == (8, 5)
+    assert np.array_equal(Runner.read_final_chain(prefix + "_chain.pkl"), chain[:, -1, :])
+
+
+def test_stretch_move_samples_a_gaussian():
+    calls = []
+
+    def log_prob(x):
+        calls.append(len(x))
+        return -0.5 * np.sum((x - 3.0) ** 2 / 4.0, axis=1)
+
+    s = EnsembleSampler(32, 3, log_prob, vectorize=True, seed=11)
+    pos, lnp, state = s.run_mcmc(np.random.default_rng(1).normal(3.0, 1.0, size=(32, 3)), 600)
+    assert calls[0] == 32 and set(calls[1:]) == {16}          # one full call, then W/2 proposals twice per step
+    assert s.chain.shape == (32, 600, 3) and s.lnprobability.shape == (32, 600) and s.iteration == 600
+    flat = s.get_chain(discard=100, flat=True)
+    assert np.all(np.abs(flat.mean(axis=0) - 3.0) < 0.25) and np.all(np.abs(flat.std(axis=0) - 2.0) < 0.3)
+    assert 0.2 < s.acceptance_fraction.mean() < 0.9
+    pos2, _, _ = s.run_mcmc(pos, 5, log_prob0=lnp, rstate0=state)
+    assert s.iteration == 605 and pos2.shape == (32, 3)
+    with pytest.raises(ValueError):
+        EnsembleSampler(4, 3, log_prob)
+    with pytest.raises(ValueError, match="NaN"):
+        EnsembleSampler(8, 2, lambda x: np.full(len(x), np.nan), vectorize=True).run_mcmc(np.zeros((8, 2)), 1)

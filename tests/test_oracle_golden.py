@@ -1,0 +1,134 @@
+"""The CPU oracle (oracle/lnprob_numpy.py) against golden vectors generated from the reference itself
+(oracle/make_golden.py, conda python 3.9 / numpy 1.26.4 / astropy 4.3.1).  This is what pins the oracle:
+the reference ships no tests or fixtures of its own.
+
+Tolerance: 1e-13 relative -- NumPy 2.2 here vs NumPy 1.26 there differ in SIMD sin/cos/log by an ulp."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import lnprob_numpy as oracle
+
+RTOL = 1e-13
+
+
+def _cat(g, extra=()):
+    return {k: g[k] for k in ("ra", "dec", "v", "verr") + tuple(extra)}
+
+
+def _split(g):
+    ok = np.isfinite(g["lnprior"])
+    return g["values"], ok
+
+
+def test_prior_pattern_matches_reference():
+    """Inclusive bounds: sigma = 0, f_back = 0 and f_back = 1 are accepted; sigma < 0, f_back > 1,
+    sigma_back < 0, dec_center = 91 deg are rejected (parameter.py:691)."""
+    from mcmc_dynamics_amd.synthetic import BOUNDS
+    for name in ("constant_fixed", "constant_free", "constant_gb_fixed", "constant_gb_free",
+                 "constant_bg_gaussian_fixed", "constant_bg_gaussian_free"):
+        g = load_golden(name)
+        lo = np.array([BOUNDS[str(n)][0] for n in g["names"]])
+        hi = np.array([BOUNDS[str(n)][1] for n in g["names"]])
+        got = np.array([oracle.bounds_lnprior(row, lo, hi) for row in g["values"]])
+        assert np.array_equal(got, g["lnprior"])
+        assert np.array_equal(np.isfinite(g["lnprob"]), np.isfinite(g["lnprior"]))
+        assert (~np.isfinite(g["lnprior"])).sum() >= 1 and np.isfinite(g["lnprior"]).sum() >= 16
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_constant_fit(which):
+    g = load_golden("constant_" + which)
+    cat = _cat(g)
+    values, ok = _split(g)
+    centre = (g["ra_center"], g["dec_center"]) if which == "fixed" else ()
+    faithful = np.array([oracle.faithful_constant_lnlike(cat, *row, *centre) for row in values[ok]])
+    assert rel_err(faithful, g["lnprob"][ok]) < RTOL
+    batched = oracle.batched_constant_lnlike(cat, values[ok], *centre)
+    assert rel_err(batched, g["lnprob"][ok]) < RTOL
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_fixed_gaussian_background(which):
+    g = load_golden("constant_bg_gaussian_" + which)
+    cat = _cat(g, ("pmember",))
+    lnbg = oracle.gaussian_background(cat["v"], cat["verr"], float(g["bg_mean"]), float(g["bg_sigma"]))
+    assert np.max(np.abs(lnbg - g["lnlike_background"])) < 1e-12          # background/gaussian.py:23-28
+    values, ok = _split(g)
+    centre = (g["ra_center"], g["dec_center"]) if which == "fixed" else ()
+    faithful = np.array([oracle.faithful_constant_lnlike(cat, *row, *centre, lnlike_background=lnbg,
+                                                         pmember=cat["pmember"]) for row in values[ok]])
+    assert rel_err(faithful, g["lnprob"][ok]) < RTOL
+    kw = dict(lnlike_background=lnbg, pmember=cat["pmember"])
+    if which == "fixed":
+        kw.update(ra_center=g["ra_center"], dec_center=g["dec_center"])
+    assert rel_err(oracle.batched_constant_lnlike(cat, values[ok], **kw), g["lnprob"][ok]) < RTOL
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_walker_gaussian_background(which):
+    g = load_golden("constant_gb_" + which)
+    cat = _cat(g, ("density",))
+    values, ok = _split(g)
+
+    def full(row):
+        if which == "fixed":
+            return tuple(row[:4]) + (g["ra_center"], g["dec_center"]) + tuple(row[4:])
+        return tuple(row)
+
+    faithful = np.array([oracle.faithful_constant_gb_lnlike(cat, *full(row)) for row in values[ok]])
+    assert rel_err(faithful, g["lnprob"][ok]) < RTOL
+    centre = (g["ra_center"], g["dec_center"]) if which == "fixed" else ()
+    assert rel_err(oracle.batched_constant_gb_lnlike(cat, values[ok], *centre), g["lnprob"][ok]) < RTOL
+    row = values[int(g["membership_row"])]
+    lc, lb, m = oracle.faithful_constant_gb_terms(cat, *full(row))
+    assert np.max(np.abs(lc - g["lnlike_cluster"]) / np.abs(g["lnlike_cluster"])) < RTOL
+    assert np.max(np.abs(lb - g["lnlike_back"]) / np.abs(g["lnlike_back"])) < RTOL
+    assert np.max(np.abs(m - g["prior_m"])) < 1e-15
+    assert np.max(np.abs(oracle.gb_membership_probabilities(cat, *full(row)) - g["membership"])) < 1e-12
+
+
+def test_radial_bins_and_per_bin_values():
+    g = load_golden("radial_bins")
+    dx, dy = oracle.calc_xy_offset(g["ra"], g["dec"], g["ra_center"], g["dec_center"])
+    r = np.sqrt(dx ** 2 + dy ** 2)
+    assert np.max(np.abs(r - g["r_arcmin"]) / g["r_arcmin"]) < 1e-12
+    assert np.array_equal(oracle.make_radial_bins(g["r_arcmin"], 200, 0.05), g["bins_n200_d005"])
+    assert np.array_equal(oracle.make_radial_bins(g["r_arcmin"], 50, 0.1), g["bins_n50_d01"])
+    bins = g["bins_n200_d005"]
+    cat = _cat(g)
+    total = np.zeros(len(g["values"]))
+    for b in range(int(bins.max()) + 1):
+        sub = {k: v[bins == b] for k, v in cat.items()}
+        got = oracle.batched_constant_lnlike(sub, g["values"], g["ra_center"], g["dec_center"])
+        assert rel_err(got, g["lnprob_per_bin"][b]) < RTOL
+        total += got
+    assert rel_err(total, g["lnprob_all"]) < RTOL        # sum over bins == un-binned (known-answer 4)
+
+
+def test_example_catalogue_adapter():
+    """example/data/test.csv is in a legacy polar layout; the adapter must hand the reference's own
+    calc_xy_offset the original (r, theta) back."""
+    g = load_golden("example_catalog")
+    assert g["r"].shape == (6284,)
+    assert np.max(np.abs(np.hypot(g["dx"], g["dy"]) - g["r"])) < 1e-9
+    assert np.max(np.abs(np.arctan2(g["dy"], g["dx"]) - g["theta"])) < 1e-9
+    cat = _cat(g)
+    got = oracle.batched_constant_lnlike(cat, g["values"], g["ra_center"], g["dec_center"])
+    assert rel_err(got, g["lnprob"]) < RTOL
+
+
+def test_closed_form_known_answer():
+    """v_max = 0: lnL = sum -1/2 [log(2 pi (e^2 + s^2)) + (v - v_sys)^2 / (e^2 + s^2)] on hand-computable stars."""
+    cat = {"ra": np.array([10.0, 10.01, 9.99]), "dec": np.array([0.0, 0.01, -0.01]),
+           "v": np.array([1.0, -2.0, 0.5]), "verr": np.array([1.0, 2.0, 0.5])}
+    v_sys, sigma = 0.25, 3.0
+    n = cat["verr"] ** 2 + sigma ** 2
+    want = np.sum(-0.5 * (np.log(2 * np.pi * n) + (cat["v"] - v_sys) ** 2 / n))
+    got = oracle.faithful_constant_lnlike(cat, v_sys, sigma, 0.0, 0.0, 10.0, 0.0)
+    assert abs(got - want) < 1e-13
+    # pmember == 1 mixture == no-background value (known-answer 2)
+    lnbg = oracle.gaussian_background(cat["v"], cat["verr"], 20.0, 40.0)
+    mix = oracle.faithful_constant_lnlike(cat, v_sys, sigma, 1.0, -0.5, 10.0, 0.0, lnbg, np.ones(3))
+    plain = oracle.faithful_constant_lnlike(cat, v_sys, sigma, 1.0, -0.5, 10.0, 0.0)
+    assert abs(mix - plain) < 1e-13
