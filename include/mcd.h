@@ -103,7 +103,9 @@ int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out);
 /* One process per GPU (torchrun-style).  Rank 0 calls mcd_get_unique_id and distributes the
  * MCD_UNIQUE_ID_BYTES blob out of band; every rank then calls mcd_ctx_create_rank.  Each rank
  * uploads ITS shard of the stars; mcd_loglike_batch all-reduces so every rank gets the total.
- * n_ranks == 1 needs no id (unique_id may be NULL) and never touches RCCL. */
+ * n_ranks == 1 needs no id (unique_id may be NULL) and never touches RCCL -- unless the environment
+ * variable MCD_FORCE_RCCL=1 is set and an id is given: then a 1-rank communicator is created and the
+ * all-reduce runs on it (lets a single-GPU box exercise the RCCL call path). */
 int mcd_get_unique_id(void* out_id);
 int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id, mcd_ctx** out);
 
@@ -155,7 +157,7 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *                      event pair per main-kernel launch for mcd_timing_collect
  *   "fast_path"     0: always use the plain per-term log/divide kernels (default 1: the fraction-tree /
  *                      log-product kernel is used whenever the per-call range guard allows it)
- *   "target_waves"  number of waves the chunking aims for per device (default 8192)
+ *   "target_waves"  number of waves the chunking aims for per device (default 16384)
  * Returns MCD_ERR_INVALID for an unknown key. */
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value);
 /* With "timing" = 2: waits for the device, returns the summed HIP-event duration (ms) of all main-kernel

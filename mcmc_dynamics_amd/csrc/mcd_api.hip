@@ -110,6 +110,7 @@ struct Shard {
     int64_t star_begin = 0;            // global index of the first star held here
     int64_t n = 0;
     void* records = nullptr;
+    double* d_pset_const = nullptr;    // BGFIXED: sum of lnlike_bg over this shard's stars of each parameter set
     std::map<int64_t, WorkSet> work;   // keyed by walker count
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
     // "timing" = 2: one (start, stop) event pair per main-kernel launch, summed by mcd_timing_collect
@@ -124,6 +125,7 @@ struct mcd_ctx {
     int rank = 0;
     int n_ranks = 1;
     bool multi_process = false;
+    bool force_collective = false;     // MCD_FORCE_RCCL=1: run the all-reduce even on a 1-rank communicator (tests)
 };
 
 struct mcd_catalog {
@@ -145,7 +147,7 @@ struct mcd_catalog {
     bool timing = false;
     bool timing_all = false;           // keep an event pair for every launch (measurement harness)
     bool allow_fast = true;
-    int64_t target_waves = 8192;
+    int64_t target_waves = 16384;
     // state of the last evaluation
     int64_t cur_walkers = 0;
     double last_kernel_ms = -1.0, last_device_ms = -1.0;
@@ -233,7 +235,7 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
 
 // Fast paths (f64 only) are valid while their intermediate products stay far from over/underflow.
 //   CONST   (fraction tree over 8 stars + log product): 2^-60 <= verr^2 + sigma^2 <= 2^60, |v - v_los| < 2^58
-//   BGFIXED / BGGAUSS (rsqrt + one exp + log product):  2^-200 <= norm <= 2^200, finite columns,
+//   BGFIXED / BGGAUSS (rsqrt + one exp + log product):  2^-200 <= norm <= 2^200, |v - v_los|^2 / norm <= 1.6e9, finite columns,
 //            lnlike_bg > -1e5, 0 <= pmember <= 1;  density >= 0, f_back >= 0, 2^-100 <= density + f_back <= 2^100
 // Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
 // expressions term by term.
@@ -266,8 +268,12 @@ bool fast_guard(const mcd_catalog* cat, const double* params, int64_t n_rows) {
         return (cat->e2_min + s2_min >= std::ldexp(1.0, -60)) && (cat->e2_max + s2_max <= std::ldexp(1.0, 60));
     const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
     if (!((cat->e2_min + s2_min >= lo) && (cat->e2_max + s2_max <= hi))) return false;
+    // exponent arguments stay below 1e9 in magnitude: (|v| + |v_los|)^2 / norm_min <= 1.6e9
+    const double d_max = cat->v_abs_max + amp;
+    if (!(d_max * d_max <= 1.6e9 * (cat->e2_min + s2_min))) return false;
     if (cat->model == MCD_MODEL_CONST_BGFIXED) return cat->extras_ok;
     if (!((cat->e2_min + sb2_min >= lo) && (cat->e2_max + sb2_max <= hi))) return false;
+    if (!(d_max * d_max <= 1.6e9 * (cat->e2_min + sb2_min))) return false;
     return cat->extras_ok && f_min >= 0.0 && (cat->rho_min + f_min >= std::ldexp(1.0, -100)) &&
            (cat->rho_max + f_max <= std::ldexp(1.0, 100));
 }
@@ -326,15 +332,17 @@ int enqueue(mcd_catalog* cat) {
             k1 = sh.ring[sh.ring_used].second;
             ++sh.ring_used;
         }
-        if (cat->timing) MCD_HIP(hipEventRecord(sh.ev_begin, slot.stream));
+        if (cat->timing && !cat->timing_all) MCD_HIP(hipEventRecord(sh.ev_begin, slot.stream));
         if (cat->timing) MCD_HIP(hipEventRecord(k0, slot.stream));
         MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, W));
         if (cat->timing) MCD_HIP(hipEventRecord(k1, slot.stream));
+        // the fast BGFIXED kernel leaves the walker-independent sum of lnL_bg to the reduction
+        const double* pset_const = (w.fast && cat->model == MCD_MODEL_CONST_BGFIXED) ? sh.d_pset_const : nullptr;
         MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, w.n_chunks,
-                                   w.max_chunks_per_pset, W, w.d_out));
+                                   w.max_chunks_per_pset, W, pset_const, w.d_out));
     }
     // sum the per-device / per-rank partial log-likelihoods: one all-reduce of n_out doubles
-    const bool collective = ctx->n_ranks > 1 || ctx->slots.size() > 1;
+    const bool collective = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
     if (collective) {
         if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
         for (Shard& sh : cat->shards) {
@@ -346,10 +354,12 @@ int enqueue(mcd_catalog* cat) {
         if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
     }
     if (cat->timing) {
-        for (Shard& sh : cat->shards) {
-            const DeviceSlot& slot = ctx->slots[sh.slot];
-            MCD_HIP(hipSetDevice(slot.device));
-            MCD_HIP(hipEventRecord(sh.ev_end, slot.stream));
+        if (!cat->timing_all) {
+            for (Shard& sh : cat->shards) {
+                const DeviceSlot& slot = ctx->slots[sh.slot];
+                MCD_HIP(hipSetDevice(slot.device));
+                MCD_HIP(hipEventRecord(sh.ev_end, slot.stream));
+            }
         }
         cat->timing_pending = true;
     }
@@ -376,9 +386,9 @@ int sync_all(mcd_catalog* cat) {
             MCD_HIP(hipEventElapsedTime(&k_ms, sh.ring[sh.ring_used - 1].first, sh.ring[sh.ring_used - 1].second));
         else
             MCD_HIP(hipEventElapsedTime(&k_ms, sh.ev_k0, sh.ev_k1));
-        MCD_HIP(hipEventElapsedTime(&d_ms, sh.ev_begin, sh.ev_end));
+        if (!cat->timing_all) MCD_HIP(hipEventElapsedTime(&d_ms, sh.ev_begin, sh.ev_end));
         cat->last_kernel_ms = k_ms;
-        cat->last_device_ms = d_ms;
+        cat->last_device_ms = cat->timing_all ? -1.0 : d_ms;
         cat->timing_pending = false;
     }
     return MCD_OK;
@@ -469,7 +479,9 @@ int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id
     ctx->slots.resize(1);
     int rc = make_slot(device, &ctx->slots[0]);
     if (rc != MCD_OK) return rc;
-    if (n_ranks > 1) {
+    const char* force = std::getenv("MCD_FORCE_RCCL");
+    ctx->force_collective = force && force[0] == '1' && unique_id;
+    if (n_ranks > 1 || ctx->force_collective) {
         if (!unique_id) return fail(MCD_ERR_INVALID, "unique_id required when n_ranks > 1");
         rc = load_rccl();
         if (rc != MCD_OK) return rc;
@@ -585,6 +597,22 @@ int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** ou
         MCD_HIP(hipEventCreate(&sh.ev_end));
         MCD_HIP(hipMalloc(&sh.records, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256)));  // slack for wide scalar loads
         MCD_HIP(hipMemsetAsync(sh.records, 0, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256), slot.stream));
+        if (d->model == MCD_MODEL_CONST_BGFIXED) {
+            std::vector<double> sums(cat->n_psets, 0.0);
+            for (int64_t p = 0; p < cat->n_psets; ++p) {
+                const int64_t b0 = std::max(cat->bin_offsets[p], sh.star_begin);
+                const int64_t b1 = std::min(cat->bin_offsets[p + 1], sh.star_begin + sh.n);
+                double sum = 0.0, comp = 0.0;                       // Neumaier-compensated
+                for (int64_t i = b0; i < b1; ++i) {
+                    const double x = d->lnlike_bg[i], t = sum + x;
+                    comp += (std::fabs(sum) >= std::fabs(x)) ? (sum - t) + x : (x - t) + sum;
+                    sum = t;
+                }
+                sums[p] = sum + comp;
+            }
+            MCD_HIP(hipMalloc(&sh.d_pset_const, sums.size() * sizeof(double)));
+            MCD_HIP(hipMemcpy(sh.d_pset_const, sums.data(), sums.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
         if (sh.n == 0) continue;
         // raw columns -> device scratch -> packed records (device-side trig), scratch freed afterwards
         const double* host_cols[7] = {d->ra, d->dec, d->v, d->verr, d->lnlike_bg, d->pmember, d->density};
@@ -613,6 +641,7 @@ int mcd_catalog_destroy(mcd_catalog* cat) {
         (void)hipStreamSynchronize(cat->ctx->slots[sh.slot].stream);
         for (auto& kv : sh.work) free_workset(kv.second);
         if (sh.records) (void)hipFree(sh.records);
+        if (sh.d_pset_const) (void)hipFree(sh.d_pset_const);
         if (sh.ev_begin) (void)hipEventDestroy(sh.ev_begin);
         if (sh.ev_k0) (void)hipEventDestroy(sh.ev_k0);
         if (sh.ev_k1) (void)hipEventDestroy(sh.ev_k1);

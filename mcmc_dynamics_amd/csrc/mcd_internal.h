@@ -43,10 +43,10 @@ hipError_t launch_prepare_walkers(hipStream_t s, const double* params, int64_t n
 hipError_t launch_loglike(hipStream_t s, const LaunchShape& shape, const void* records, const Chunk* chunks,
                           int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers);
 
-// out[pset][w] = sum over the chunks of pset of partials[w][chunk]  (fixed order)
+// out[pset][w] = sum over the chunks of pset of partials[w][chunk]  (fixed order) [+ pset_const[pset]]
 hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* pset_chunk_offsets,
                          int64_t n_psets, int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers,
-                         double* out);
+                         const double* pset_const, double* out);
 
 hipError_t launch_membership(hipStream_t s, const LaunchShape& shape, const void* records, int64_t n,
                              const void* wpar_row, double* out);

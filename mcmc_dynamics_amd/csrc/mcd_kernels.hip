@@ -134,7 +134,8 @@ __device__ __forceinline__ double wave_sum(double x) {
 
 __global__ __launch_bounds__(kBlock) void reduce_wide_kernel(const double* __restrict__ partials,
                                                               const int64_t* __restrict__ offs, int64_t n_chunks,
-                                                              int64_t n_walkers, double* __restrict__ out) {
+                                                              int64_t n_walkers, const double* __restrict__ pset_const,
+                                                              double* __restrict__ out) {
     __shared__ double lds[kWavesPerBlock];
     const int64_t o = blockIdx.x;
     const int64_t pset = o / n_walkers, w = o - pset * n_walkers;
@@ -145,13 +146,17 @@ __global__ __launch_bounds__(kBlock) void reduce_wide_kernel(const double* __res
     acc = wave_sum(acc);
     if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[o] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    if (threadIdx.x == 0) {
+        const double c = pset_const ? pset_const[pset] : 0.0;     // walker-independent part (sum of lnL_bg)
+        out[o] = ((lds[0] + lds[1]) + (lds[2] + lds[3])) + c;
+    }
 }
 
 // narrow form: one thread per output, few chunks per parameter set (radial bins)
 __global__ __launch_bounds__(kBlock) void reduce_narrow_kernel(const double* __restrict__ partials,
                                                                 const int64_t* __restrict__ offs, int64_t n_psets,
                                                                 int64_t n_chunks, int64_t n_walkers,
+                                                                const double* __restrict__ pset_const,
                                                                 double* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= n_psets * n_walkers) return;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void reduce_narrow_kernel(const double* __r
     const double* __restrict__ row = partials + w * n_chunks;
     double acc = 0.0;
     for (int64_t c = c0; c < c1; ++c) acc += row[c];
-    out[pset * n_walkers + w] = acc;
+    out[pset * n_walkers + w] = acc + (pset_const ? pset_const[pset] : 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,16 +268,17 @@ hipError_t launch_loglike(hipStream_t s, const LaunchShape& sh, const void* reco
 }
 
 hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* offs, int64_t n_psets,
-                         int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers, double* out) {
+                         int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers, const double* pset_const,
+                         double* out) {
     const int64_t n_out = n_psets * n_walkers;
     if (n_out <= 0) return hipSuccess;
     if (max_chunks_per_pset > 16) {
         hipLaunchKernelGGL(reduce_wide_kernel, dim3((unsigned)n_out), dim3(kBlock), 0, s, partials, offs, n_chunks,
-                           n_walkers, out);
+                           n_walkers, pset_const, out);
     } else {
         const unsigned grid = (unsigned)((n_out + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(reduce_narrow_kernel, dim3(grid), dim3(kBlock), 0, s, partials, offs, n_psets, n_chunks,
-                           n_walkers, out);
+                           n_walkers, pset_const, out);
     }
     return hipGetLastError();
 }

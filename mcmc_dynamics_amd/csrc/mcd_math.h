@@ -65,7 +65,9 @@ MCD_HD float fma_(float a, float b, float c) {
 // sin(theta), cos(theta) of the position angle about a walker's centre from the star's and the
 // centre's sines/cosines (angle-addition form of calc_xy_offset.py:30-31 followed by
 // arctan2, constant.py:106-107; the r0 factor cancels).  r == 0 follows numpy's arctan2(+0, -0) = pi.
-template <class T>
+MCD_HD double rsqrt_nr(double n);
+
+template <bool FASTMATH, class T>
 MCD_HD void free_centre_geometry(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T cdc, T& s, T& c) {
     T sin_dra = fma_(sa, cac, -(ca * sac));
     T cos_dra = fma_(ca, cac, sa * sac);
@@ -73,11 +75,16 @@ MCD_HD void free_centre_geometry(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T 
     T y = fma_(sd, cdc, -(cd * sdc * cos_dra));
     T r2 = fma_(x, x, y * y);
     if (r2 > T(0)) {
+        T inv;
+        if constexpr (FASTMATH && sizeof(T) == 8) {
+            inv = (T)rsqrt_nr((double)r2);        // offsets are O(1e-9 .. 1) rad: r2 is a normal number
+        } else {
 #if defined(__HIP_DEVICE_COMPILE__)
-        T inv = T(1) / sqrt(r2);
+            inv = T(1) / sqrt(r2);
 #else
-        T inv = T(1) / std::sqrt(r2);
+            inv = T(1) / std::sqrt(r2);
 #endif
+        }
         s = y * inv;
         c = x * inv;
     } else {
@@ -94,8 +101,9 @@ MCD_HD void free_centre_geometry(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T 
 // summing individually rounded logs.
 struct LogProduct {
     double p;
-    int64_t e;
-    MCD_HD void init() { p = 1.0; e = 0; }
+    int64_t e;     // exponent carried over from finished groups
+    int e32;       // exponent of the current group (folded into e by rescale(); |e32| stays far below 2^31)
+    MCD_HD void init() { p = 1.0; e = 0; e32 = 0; }
     MCD_HD void mul(double x) { p *= x; }            // caller keeps |log2 p| < ~1000 between rescales
     MCD_HD void rescale() {
         int ex;
@@ -104,7 +112,8 @@ struct LogProduct {
 #else
         p = std::frexp(p, &ex);
 #endif
-        e += ex;
+        e += (int64_t)(e32 + ex);
+        e32 = 0;
     }
     MCD_HD void mul_any(double x) {                  // any positive finite x: split first
         int ex;
@@ -114,7 +123,7 @@ struct LogProduct {
         double m = std::frexp(x, &ex);
 #endif
         p *= m;
-        e += ex;
+        e32 += ex;
     }
     MCD_HD double value() {
         rescale();
@@ -203,20 +212,20 @@ MCD_HD T mixture_lnl(T m, T b, T p) {
 
 MCD_HD double rsqrt_nr(double n) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double y = __builtin_amdgcn_rsq(n);
+    double y = __builtin_amdgcn_rsq(n);      // v_rsq_f64: measured max rel. error 2^-24.2 on gfx950 (tools/rsq_probe.hip)
 #else
     double y = 1.0 / std::sqrt(n);
 #endif
-    // y <- y + y (1 - n y^2) / 2, twice: 2^-23 -> 2^-45 -> full f64
-    double e = fma_(-(n * y), y, 1.0);
-    y = fma_(y, 0.5 * e, y);
-    e = fma_(-(n * y), y, 1.0);
-    y = fma_(y, 0.5 * e, y);
-    return y;
+    // one third-order step: with e = 1 - n y^2 (|e| <= 2^-23.2),  n^-1/2 = y (1 + e/2 + 3 e^2/8 + O(e^3)),
+    // remaining error 5/16 e^3 < 2^-71: full f64 after the final rounding.  5 instructions.
+    const double e = fma_(-(n * y), y, 1.0);
+    const double t = fma_(0.375, e, 0.5);
+    return fma_(y, t * e, y);
 }
 
 // e^u = 2^k e^r with k = rint(u / ln 2), |r| <= ln2 / 2; returns the mantissa part e^r and k.
-// Taylor to r^13 / 13!: truncation error 4e-18 on the reduced range.
+// Polynomial: Taylor series to r^13 Chebyshev-economised to degree 11 on [-0.35, 0.35] (exact rational
+// arithmetic, then rounded to f64): approximation error 1.1e-17, 1.3e-16 with f64 Horner rounding.
 MCD_HD double exp_split(double u, int& k_out) {
     constexpr double kLog2e = 1.442695040888963407359924681;
     constexpr double kLn2Hi = 6.93147180369123816490e-01;    // high 32 bits of ln 2 (k * hi is exact)
@@ -228,18 +237,16 @@ MCD_HD double exp_split(double u, int& k_out) {
 #endif
     double r = fma_(-kf, kLn2Hi, u);
     r = fma_(-kf, kLn2Lo, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma_(p, r, 1.0 / 479001600.0);
-    p = fma_(p, r, 1.0 / 39916800.0);
-    p = fma_(p, r, 1.0 / 3628800.0);
-    p = fma_(p, r, 1.0 / 362880.0);
-    p = fma_(p, r, 1.0 / 40320.0);
-    p = fma_(p, r, 1.0 / 5040.0);
-    p = fma_(p, r, 1.0 / 720.0);
-    p = fma_(p, r, 1.0 / 120.0);
-    p = fma_(p, r, 1.0 / 24.0);
-    p = fma_(p, r, 1.0 / 6.0);
-    p = fma_(p, r, 0.5);
+    double p = 2.5116043453717065e-08;
+    p = fma_(p, r, 2.7634041305916304e-07);
+    p = fma_(p, r, 2.7557221323412594e-06);
+    p = fma_(p, r, 2.4801481568968142e-05);
+    p = fma_(p, r, 0.00019841269913226762);
+    p = fma_(p, r, 0.0013888888956048683);
+    p = fma_(p, r, 0.008333333333307623);
+    p = fma_(p, r, 0.041666666666473846);
+    p = fma_(p, r, 0.16666666666666707);
+    p = fma_(p, r, 0.500000000000002);
     p = fma_(p, r, 1.0);
     p = fma_(p, r, 1.0);
     k_out = (int)kf;
@@ -253,32 +260,38 @@ MCD_HD double ldexp_(double x, int k) {
     return std::ldexp(x, k);
 #endif
 }
-MCD_HD double clamp_(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+MCD_HD double fmax_(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmax(a, b);              // v_max_f64
+#else
+    return std::fmax(a, b);
+#endif
+}
 
 // MODEL_BGFIXED: lnL_i = b_i + log((1 - p_i) + p_i t_i),  t_i = exp(m_i - b_i) = g exp(-1/2 q g^2 - b'_i),
 // b'_i = b_i + 1/2 log 2pi  (the record carries nbp = -b'_i).  Same value as runner.py:280-286.
 struct BgFixedAcc {
-    double sum_b;          // sum b_i
-    LogProduct l;          // sum log y_i
-    MCD_HD void init() { sum_b = 0.0; l.init(); }
-    MCD_HD void add(double d, double n, double b, double p, double omp, double nbp) {
+    LogProduct l;          // sum log y_i   (sum b_i is walker-independent: added once per parameter set by the reduce kernel)
+    MCD_HD void init() { l.init(); }
+    MCD_HD void add(double d, double n, double p, double omp, double nbp) {
         const double g = rsqrt_nr(n);
-        const double w = (d * d) * (g * g);
-        double u = fma_(-0.5, w, nbp);
-        u = clamp_(u, -1.0e6, 1.0e6);            // keeps k inside int range; exactness unaffected (see below)
+        const double dg = d * g;
+        // |u| <= 1e9 by the host guard (|v - v_los| / sqrt(norm) <= 4e4, |lnL_bg| <= 1e5): k fits an int and e^u
+        // is an exact 0 long before the range reduction loses accuracy.
+        const double u = fma_(-0.5 * dg, dg, nbp);
         int k;
         const double er = exp_split(u, k);
-        const double x = p * (g * er);
-        // y = (1 - p) + x 2^k.  Exponents beyond +-1000 are carried in the integer part of the product:
-        // for k > 1000 the (1 - p) term is below 2^-900 of y and drops out exactly as it would in f64.
-        const int kc = k < -1000 ? -1000 : (k > 1000 ? 1000 : k);
-        const double y = omp + ldexp_(x, kc);
+        // y = (1 - p) + p g e^r 2^k.  k > 1000 (cluster likelihood e^693 times the background's) is carried in the
+        // integer part of the product: there the (1 - p) term is below 2^-900 of y and drops out exactly as in f64.
+        // k < -1074 underflows inside ldexp; with p == 1 exactly that gives y = 0 and lnL = -inf, which is also what
+        // the reference returns there (runner.py:283: log(1 * exp(m - b) + 0) with exp underflowing).
+        const int kc = k > 1000 ? 1000 : k;
+        const double y = fma_(p * g, ldexp_(er, kc), omp);
         l.mul_any(y);
-        l.e += (k > kc) ? (k - kc) : 0;
-        sum_b += b;
+        l.e32 += k - kc;
     }
     MCD_HD void rescale() { l.rescale(); }
-    MCD_HD double finish() { return sum_b + l.value(); }
+    MCD_HD double finish() { return l.value(); }
 };
 
 // MODEL_BGGAUSS (constant.py:320-364):
@@ -293,15 +306,16 @@ struct BgGaussAcc {
     MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); }
     MCD_HD void add(double d, double n, double db, double nb, double rho, double f) {
         const double g = rsqrt_nr(n), gb = rsqrt_nr(nb);
-        const double w = (d * d) * (g * g), wb = (db * db) * (gb * gb);
+        const double dg = d * g, dbg = db * gb;
+        const double w = dg * dg, wb = dbg * dbg;
         const bool cluster_big = w <= wb;                 // cluster exponent -w/2 is the larger one
         const double delta = cluster_big ? (wb - w) : (w - wb);
-        double u = -0.5 * delta;
-        u = u < -1.0e4 ? -1.0e4 : u;
-        int k;
-        const double er = exp_split(u, k);
-        const double e = ldexp_(er, k);                    // underflows to 0 harmlessly
+        int k;                                            // delta <= 2e9 by the host guard
+        const double er = exp_split(-0.5 * delta, k);
+        const double e = ldexp_(er, k);                    // k <= 0: underflows to 0 inside ldexp
         const double a = rho * g, b = f * gb;
+        // if the undamped component is exactly zero (f_back = 0 or density = 0) and e^{-delta} underflows, y = 0 and
+        // lnL = -inf -- the same as the reference's log-sum-exp about the larger exponent (constant.py:320-323).
         const double y = cluster_big ? fma_(b, e, a) : fma_(a, e, b);
         ly.mul_any(y);
         lden.mul(rho + f);
@@ -320,10 +334,10 @@ template <class T> struct WalkerConsts {
     T vsys, s2, vx, vy, sac, cac, sdc, cdc, vb, sb2, fb;
 };
 
-template <class T, bool FREE>
+template <class T, bool FREE, bool FASTMATH = false>
 MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T& n) {
     T s, c;
-    if (FREE) free_centre_geometry(r[2], r[3], r[4], r[5], w.sac, w.cac, w.sdc, w.cdc, s, c);
+    if (FREE) free_centre_geometry<FASTMATH>(r[2], r[3], r[4], r[5], w.sac, w.cac, w.sdc, w.cdc, s, c);
     else { s = r[2]; c = r[3]; }
     // v - (v_sys + v_maxx sin(theta) - v_maxy cos(theta))
     d = fma_(-w.vx, s, fma_(w.vy, c, r[0] - w.vsys));
@@ -345,14 +359,14 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 double d;
-                star_d_n<double, FREE>(r + j * ND, w, d, nn[j]);
+                star_d_n<double, FREE, true>(r + j * ND, w, d, nn[j]);
                 qq[j] = d * d;
             }
             acc.add8(qq, nn);
         }
         for (int j = n8 * 8; j < count; ++j, r += ND) {
             double d, n;
-            star_d_n<double, FREE>(r, w, d, n);
+            star_d_n<double, FREE, true>(r, w, d, n);
             acc.add1(d * d, n);
         }
         result = acc.finish(count);
@@ -377,15 +391,16 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             for (int j = 0; j < 4; ++j) {
                 const double* rr = r + j * ND;
                 double d, n;
-                star_d_n<double, FREE>(rr, w, d, n);
-                acc.add(d, n, rr[XB], rr[XB + 1], rr[XB + 2], rr[XB + 3]);
+                star_d_n<double, FREE, true>(rr, w, d, n);
+                acc.add(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3]);
             }
             acc.rescale();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
-            star_d_n<double, FREE>(r, w, d, n);
-            acc.add(d, n, r[XB], r[XB + 1], r[XB + 2], r[XB + 3]);
+            star_d_n<double, FREE, true>(r, w, d, n);
+            acc.add(d, n, r[XB + 1], r[XB + 2], r[XB + 3]);
+            acc.rescale();
         }
         result = acc.finish();
     } else if constexpr (MODEL == MODEL_BGGAUSS && FAST) {
@@ -398,14 +413,14 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             for (int j = 0; j < 4; ++j) {
                 const double* rr = r + j * ND;
                 double d, n;
-                star_d_n<double, FREE>(rr, w, d, n);
+                star_d_n<double, FREE, true>(rr, w, d, n);
                 acc.add(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb);
             }
             acc.rescale();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
-            star_d_n<double, FREE>(r, w, d, n);
+            star_d_n<double, FREE, true>(r, w, d, n);
             acc.add(d, n, r[0] - w.vb, r[1] + w.sb2, r[XB], w.fb);
             acc.rescale();
         }

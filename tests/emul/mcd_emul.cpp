@@ -22,6 +22,12 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
             const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
             total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c);
         }
+        if (MODEL == MODEL_BGFIXED && FAST) {        // walker-independent sum of lnL_bg: added by the reduce kernel on the GPU
+            constexpr int XB = FREE ? 6 : 4;
+            double sb = 0.0;
+            for (int64_t i = 0; i < n; ++i) sb += recs[i * ND + XB];
+            total += sb;
+        }
         out[w] = total;
     }
 }

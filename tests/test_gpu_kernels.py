@@ -260,3 +260,26 @@ def test_rank_mode_context_single_rank(native):
     b = native.Catalog(native.default_context(), c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST,
                        centre=centre).loglike(pos)
     assert np.array_equal(a, b)
+
+
+def test_rccl_call_path_on_one_rank(native):
+    """MCD_FORCE_RCCL=1: unique id -> ncclCommInitRank(1 rank) -> ncclAllReduce(sum, f64) on the catalogue's
+    stream.  Exercises librccl loading and the collective call site on a single GPU; sums are unchanged."""
+    import os
+    from mcmc_dynamics_amd import synthetic
+    c, centre = _synthetic(5000, 4)
+    pos = synthetic.make_walkers(128, NAMES4, c["truth"], config=4)
+    ref = native.Catalog(native.default_context(), c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST,
+                         centre=centre).loglike(pos)
+    os.environ["MCD_FORCE_RCCL"] = "1"
+    try:
+        uid = native.Context.unique_id()
+        assert len(uid) == native.UNIQUE_ID_BYTES and any(uid)
+        ctx1 = native.Context(rank=0, n_ranks=1, unique_id=uid, device=0)
+    finally:
+        del os.environ["MCD_FORCE_RCCL"]
+    cat = native.Catalog(ctx1, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
+    for _ in range(3):
+        assert np.array_equal(cat.loglike(pos), ref)
+    cat.close()
+    ctx1.close()

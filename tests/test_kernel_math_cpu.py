@@ -46,3 +46,34 @@ def test_fast_paths_survive_outliers_and_extreme_backgrounds():
     fast = emul.loglike(cat, g["values"][ok], 1, centre, 1)
     assert np.all(np.isfinite(plain))
     assert rel_err(fast, plain) < RTOL
+
+
+def test_fast_mixtures_share_the_reference_underflow_behaviour():
+    """pmember == 1 with a 90-sigma outlier, or f_back == 0 with a star the cluster model rejects: the
+    reference's log-sum-exp about max(m, b) underflows to log(0) = -inf (runner.py:282-284,
+    constant.py:320-323).  The single-exp formulation must give -inf for the same walkers and agree on the rest."""
+    g = load_golden("constant_bg_gaussian_fixed")
+    cat = {k: g[k].copy() for k in ("ra", "dec", "v", "verr", "pmember")}
+    cat["lnlike_bg"] = g["lnlike_background"].copy()
+    centre = (float(g["ra_center"]), float(g["dec_center"]))
+    ok = np.isfinite(g["lnprior"]) & (g["values"][:, 1] > 0)
+    cat["pmember"][:3] = 1.0
+    cat["pmember"][3] = 0.0
+    cat["v"][:3] = [60.0, -45.0, 80.0]                   # certain members, moderate outliers: finite
+    plain = emul.loglike(cat, g["values"][ok], 1, centre, 0)
+    assert np.all(np.isfinite(plain))
+    assert rel_err(emul.loglike(cat, g["values"][ok], 1, centre, 1), plain) < RTOL
+    cat["v"][:3] = [900.0, -1500.0, 4000.0]              # certain members, > 38 sigma: exp underflows in the reference
+    plain = emul.loglike(cat, g["values"][ok], 1, centre, 0)
+    assert np.all(np.isneginf(plain))
+    assert np.all(np.isneginf(emul.loglike(cat, g["values"][ok], 1, centre, 1)))
+
+    g = load_golden("constant_gb_fixed")
+    cat = {k: g[k].copy() for k in ("ra", "dec", "v", "verr", "density")}
+    cat["v"][:3] = [900.0, -1500.0, 4000.0]
+    vals = g["values"][np.isfinite(g["lnprior"]) & (g["values"][:, 1] > 0) & (g["values"][:, 5] > 0)].copy()
+    vals[:4, 6] = 0.0                                    # f_back = 0 with extreme outliers: -inf in the reference
+    vals[4:8, 5] = 3.0                                   # narrow background: the damped term underflows harmlessly
+    plain = emul.loglike(cat, vals, 2, centre, 0)
+    assert np.all(np.isneginf(plain[:4])) and np.isfinite(plain[4:]).sum() >= 8
+    assert rel_err(emul.loglike(cat, vals, 2, centre, 1), plain) < RTOL
