@@ -14,7 +14,7 @@
  *                        `Runner._calculate_lnlike` (analysis/constant.py:113-154, :293-364;
  *                        analysis/runner.py:240-286) for W walkers per call.
  *   mcd_membership       replaces `ConstantFitGB.calculate_membership_probabilities`
- *                        (analysis/constant.py:366-374).
+ *                        (analysis/constant.py:366-374) and the ModelFit variants (analysis/model.py:458-510, 625-687).
  *
  * Conventions
  *   - plain pointers and sizes only; all arrays are float64 unless stated; canonical units of the
@@ -56,9 +56,12 @@ typedef enum {
                                      (runner.py:272-286; background/gaussian.py:23-28)              */
     MCD_MODEL_CONST_BGGAUSS = 2,  /* ConstantFitGB: per-walker (v_back, sigma_back, f_back) and the
                                      `density` prior (constant.py:293-364)                          */
-    MCD_MODEL_PROFILE = 3,        /* ModelFit: Lynden-Bell rotation curve + Plummer dispersion
-                                     (analysis/model.py:93-180); needs per-star radius              */
-    MCD_MODEL_PROFILE_BGGAUSS = 4 /* ModelFitGB (analysis/model.py:391-456)                          */
+    MCD_MODEL_PROFILE = 3,        /* ModelFit: Lynden-Bell rotation curve + Plummer dispersion profile
+                                     (analysis/model.py:93-222)                                     */
+    MCD_MODEL_PROFILE_BGGAUSS = 4,/* ModelFitGB: + per-walker Gaussian background, density prior
+                                     (analysis/model.py:391-456)                                    */
+    MCD_MODEL_PROFILE_BGDENS = 5  /* ModelFitConstantBackground: fixed per-star background lnL, density prior
+                                     with per-walker f_back (analysis/model.py:565-623)             */
 } mcd_model;
 
 typedef enum {
@@ -79,9 +82,9 @@ typedef struct {
     const double* dec;        /* deg  */
     const double* v;          /* km/s */
     const double* verr;       /* km/s */
-    const double* lnlike_bg;  /* MCD_MODEL_CONST_BGFIXED: background(v, verr) per star            */
-    const double* pmember;    /* MCD_MODEL_CONST_BGFIXED: prior membership probability            */
-    const double* density;    /* *_BGGAUSS: normalised stellar surface density                     */
+    const double* lnlike_bg;  /* CONST_BGFIXED, PROFILE_BGDENS: background(v, verr) per star       */
+    const double* pmember;    /* CONST_BGFIXED: prior membership probability                       */
+    const double* density;    /* *_BGGAUSS, PROFILE_BGDENS: normalised stellar surface density     */
     int32_t model;            /* mcd_model     */
     int32_t centre;           /* mcd_centre    */
     int32_t precision;        /* mcd_precision */
@@ -121,8 +124,9 @@ int mcd_catalog_destroy(mcd_catalog* cat);
  *   CONST    : v_sys, sigma_max, v_maxx, v_maxy [, ra_center, dec_center]
  *   *_BGGAUSS: ... + v_back, sigma_back, f_back
  *   PROFILE  : v_sys, sigma_max, a, v_maxx, v_maxy, r_peak [, ra_center, dec_center] (a, r_peak in arcsec)
- * (order of config/constant.json:6-11, constant_with_background.json:6-14, model.json:6-13 with the
- * centre moved behind the model parameters). */
+ *   PROFILE_BGGAUSS: ... + v_back, sigma_back, f_back        PROFILE_BGDENS: ... + f_back
+ * (order of config/constant.json:6-11, constant_with_background.json:6-14, model_with_background.json:6-16;
+ * config/model.json interleaves the centre between v_maxx and v_maxy -- the host maps columns by name). */
 int mcd_catalog_param_count(const mcd_catalog* cat);
 int64_t mcd_catalog_n_stars(const mcd_catalog* cat);      /* stars held by THIS process */
 int64_t mcd_catalog_n_outputs(const mcd_catalog* cat, int64_t n_walkers); /* W * max(1, n_bins) */
@@ -143,6 +147,9 @@ int mcd_sync(mcd_catalog* cat);
 /* Posterior membership probability per star for ONE parameter row (BGGAUSS models):
  * m e^{lc} / (m e^{lc} + (1 - m) e^{lb}); out has n_stars doubles (this process' shard). */
 int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* out);
+/* Per-star mixture log-likelihood for ONE parameter row, `lnlike(values, no_sum=True)` of
+ * ModelFitConstantBackground (analysis/model.py:565-623); defined for every background model. */
+int mcd_loglike_per_star(mcd_catalog* cat, int32_t k, const double* params, double* out);
 
 /* ---- introspection for the measurement harness ------------------------------------------- */
 

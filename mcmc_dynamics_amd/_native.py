@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcd_hip.so")
 
 MODEL_CONST, MODEL_CONST_BGFIXED, MODEL_CONST_BGGAUSS = 0, 1, 2
+MODEL_PROFILE, MODEL_PROFILE_BGGAUSS, MODEL_PROFILE_BGDENS = 3, 4, 5
 CENTRE_FIXED, CENTRE_FREE = 0, 1
 F64, F32, F32_ACC64 = 0, 1, 2
 PRECISIONS = {"f64": F64, "f32": F32, "f32acc64": F32_ACC64}
@@ -41,6 +42,7 @@ SYMBOLS = {
     "mcd_loglike_fetch": (ctypes.c_int, [ctypes.c_void_p, _c_double_p]),
     "mcd_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_membership": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_double_p, _c_double_p]),
+    "mcd_loglike_per_star": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_double_p, _c_double_p]),
     "mcd_last_error": (ctypes.c_char_p, []),
     "mcd_abi_version": (ctypes.c_int, []),
     "mcd_last_kernel_ms": (ctypes.c_double, [ctypes.c_void_p]),
@@ -276,6 +278,12 @@ class Catalog(object):
         p = _f64(params_row).reshape(-1)
         out = np.empty(self.n_stars, dtype=np.float64)
         _check(self.lib, self.lib.mcd_membership(self.handle, p.size, _ptr(p), _ptr(out)), "mcd_membership")
+        return out
+
+    def loglike_per_star(self, params_row):
+        p = _f64(params_row).reshape(-1)
+        out = np.empty(self.n_stars, dtype=np.float64)
+        _check(self.lib, self.lib.mcd_loglike_per_star(self.handle, p.size, _ptr(p), _ptr(out)), "mcd_loglike_per_star")
         return out
 
     def set_option(self, key, value):

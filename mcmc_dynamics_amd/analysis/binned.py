@@ -99,15 +99,8 @@ class BinnedConstantFit(ConstantFit):
         if self.background is not None:
             raise IOError("BinnedConstantFit does not take a background population.")
 
-    def _ensure_catalog(self):
-        key, spec = self._catalog_spec()
-        if self._catalog is None or key != self._catalog_key:
-            if self._catalog is not None:
-                self._catalog.close()
-            self._catalog = _native.Catalog(self.context, self.ra, self.dec, self.v, self.verr,
-                                            precision=self._precision, bin_offsets=self.bin_offsets, **spec)
-            self._catalog_key = key
-        return self._catalog
+    def _catalog_kwargs(self):
+        return {"bin_offsets": self.bin_offsets}
 
     def _resolve(self, values):
         values = np.asarray(values, dtype=np.float64)
@@ -120,7 +113,7 @@ class BinnedConstantFit(ConstantFit):
 
     def _launch(self, w, flat):
         cat = self._ensure_catalog()
-        table = np.stack(self._kernel_table(flat, self._catalog_key[1] is None), axis=1)
+        table = self._kernel_table(flat)
         return cat.loglike(table.reshape(self.n_bins, w, -1)) if self.n_bins > 1 else \
             cat.loglike(table.reshape(w, -1))[None, :]
 

@@ -93,48 +93,13 @@ class ConstantFit(Runner):
         theta_0 = np.arctan2(v_maxy, v_maxx)
         return v_sys + v_max * np.sin(theta - theta_0)
 
-    # ------------------------------------------------------------------ GPU evaluation
-    def _centre_is_fixed(self):
-        pr, pd = self.parameters["ra_center"], self.parameters["dec_center"]
-        return pr.fixed and pd.fixed and pr.expr is None and pd.expr is None
+    # ------------------------------------------------------------------ GPU evaluation (plumbing in Runner)
+    _KERNEL_HEAD = (("v_sys", "km/s"), ("sigma_max", "km/s"), ("v_maxx", "km/s"), ("v_maxy", "km/s"))
 
-    def _catalog_spec(self):
-        """(key, constructor kwargs) of the device catalogue for the current parameter configuration."""
-        if self._centre_is_fixed():
-            centre = (float(self.parameters["ra_center"].value), float(self.parameters["dec_center"].value))
-        else:
-            centre = None
-        model = self._model_id
-        extra = {}
-        if self.background is not None and model == _native.MODEL_CONST:
-            model = _native.MODEL_CONST_BGFIXED
-            extra = {"lnlike_bg": self.lnlike_background, "pmember": self.pmember}
-        return (model, centre), dict(model=model, centre=centre, **extra)
-
-    def _ensure_catalog(self):
-        key, spec = self._catalog_spec()
-        if self._catalog is None or key != self._catalog_key:
-            if self._catalog is not None:
-                self._catalog.close()
-            self._catalog = _native.Catalog(self.context, self.ra, self.dec, self.v, self.verr,
-                                            precision=self._precision, **self._extra_columns(), **spec)
-            self._catalog_key = key
-        return self._catalog
-
-    def _extra_columns(self):
-        return {}
-
-    def _kernel_table(self, resolved, free_centre):
-        cols = [self._canonical(resolved, "v_sys", "km/s"), self._canonical(resolved, "sigma_max", "km/s"),
-                self._canonical(resolved, "v_maxx", "km/s"), self._canonical(resolved, "v_maxy", "km/s")]
-        if free_centre:
-            cols += [self._canonical(resolved, "ra_center", "deg"), self._canonical(resolved, "dec_center", "deg")]
-        return cols
-
-    def _lnlike_batch(self, resolved):
-        cat = self._ensure_catalog()
-        table = np.stack(self._kernel_table(resolved, self._catalog_key[1] is None), axis=1)
-        return cat.loglike(table)
+    def _catalog_model(self):
+        if self.background is not None and self._model_id == _native.MODEL_CONST:
+            return _native.MODEL_CONST_BGFIXED, {"lnlike_bg": self.lnlike_background, "pmember": self.pmember}
+        return self._model_id, {}
 
     def lnlike(self, values):
         """Log-likelihood of the data for one parameter vector (constant.py:113-154)."""
@@ -174,13 +139,10 @@ class ConstantFitGB(ConstantFit):
             logger.error("Class ConstantFitGB does not support additional background components.")
         super(ConstantFitGB, self).__init__(data=data, parameters=parameters, **kwargs)
 
-    def _extra_columns(self):
-        return {"density": self.density}
+    _KERNEL_TAIL = (("v_back", "km/s"), ("sigma_back", "km/s"), ("f_back", None))
 
-    def _kernel_table(self, resolved, free_centre):
-        cols = super(ConstantFitGB, self)._kernel_table(resolved, free_centre)
-        return cols + [self._canonical(resolved, "v_back", "km/s"), self._canonical(resolved, "sigma_back", "km/s"),
-                       resolved["f_back"]]
+    def _catalog_model(self):
+        return self._model_id, {"density": self.density}
 
     def lnlike(self, values):
         """Log-likelihood including the Gaussian background mixture (constant.py:293-324)."""
@@ -195,7 +157,4 @@ class ConstantFitGB(ConstantFit):
 
     def membership_probabilities(self, values):
         """m e^{lnL_cluster} / (m e^{lnL_cluster} + (1 - m) e^{lnL_back}) for one parameter vector."""
-        resolved = self.parameters.resolve_batch(np.asarray(values, dtype=np.float64).reshape(1, -1))
-        cat = self._ensure_catalog()
-        row = np.stack(self._kernel_table(resolved, self._catalog_key[1] is None), axis=1)[0]
-        return cat.membership(row)
+        return self._per_star(values, "membership")

@@ -192,9 +192,6 @@ class Runner(object):
         out[ok] = ll[ok] + lp[ok]
         return out
 
-    def _lnlike_batch(self, resolved):
-        raise NotImplementedError
-
     # ------------------------------------------------------------------ sampler driver
     def get_initials(self, n_walkers):
         """Initial positions from each free parameter's ``initials`` recipe (runner.py:308-330)."""
@@ -353,10 +350,67 @@ class Runner(object):
         return flat[idx]
 
     # ------------------------------------------------------------------ device catalogue
+    # Sub-classes set `_model_id` and the ordered (name, canonical unit) columns of the kernel's parameter
+    # table before (`_KERNEL_HEAD`) and after (`_KERNEL_TAIL`) the optional centre columns (include/mcd.h).
+    _model_id = None
+    _KERNEL_HEAD = ()
+    _KERNEL_TAIL = ()
+
     def _canonical(self, resolved, name, unit):
         """Resolved column of parameter ``name`` expressed in the kernel's canonical unit."""
         f = units.conversion_factor(self.parameters[name].unit, unit) if self.parameters[name].unit else 1.0
         return resolved[name] if f == 1.0 else resolved[name] * f
+
+    def _centre_is_fixed(self):
+        pr, pd = self.parameters["ra_center"], self.parameters["dec_center"]
+        return pr.fixed and pd.fixed and pr.expr is None and pd.expr is None
+
+    def _catalog_model(self):
+        """(model id, extra per-star columns) of the device catalogue."""
+        return self._model_id, {}
+
+    def _catalog_spec(self):
+        """(key, constructor kwargs) of the device catalogue for the current parameter configuration:
+        a fixed centre lets the walker-independent geometry be precomputed at upload."""
+        if self._centre_is_fixed():
+            centre = (float(units.to_unit(self.parameters["ra_center"].value, "deg", self.parameters["ra_center"].unit)),
+                      float(units.to_unit(self.parameters["dec_center"].value, "deg", self.parameters["dec_center"].unit)))
+        else:
+            centre = None
+        model, extra = self._catalog_model()
+        return (model, centre), dict(model=model, centre=centre, **extra)
+
+    def _catalog_kwargs(self):
+        return {}
+
+    def _ensure_catalog(self):
+        key, spec = self._catalog_spec()
+        if self._catalog is None or key != self._catalog_key:
+            if self._catalog is not None:
+                self._catalog.close()
+            self._catalog = _native.Catalog(self.context, self.ra, self.dec, self.v, self.verr,
+                                            precision=self._precision, **self._catalog_kwargs(), **spec)
+            self._catalog_key = key
+        return self._catalog
+
+    def _kernel_table(self, resolved):
+        """(W, K) float64 table in the column order and canonical units the C-ABI expects."""
+        cols = [self._canonical(resolved, n, u) for n, u in self._KERNEL_HEAD]
+        if self._catalog_key[1] is None:
+            cols += [self._canonical(resolved, "ra_center", "deg"), self._canonical(resolved, "dec_center", "deg")]
+        cols += [self._canonical(resolved, n, u) for n, u in self._KERNEL_TAIL]
+        return np.stack(cols, axis=1)
+
+    def _lnlike_batch(self, resolved):
+        cat = self._ensure_catalog()
+        return cat.loglike(self._kernel_table(resolved))
+
+    def _per_star(self, values, what):
+        """Per-star device outputs for ONE parameter vector: 'membership' or 'lnlike'."""
+        resolved = self.parameters.resolve_batch(np.asarray(values, dtype=np.float64).reshape(1, -1))
+        cat = self._ensure_catalog()
+        row = self._kernel_table(resolved)[0]
+        return cat.membership(row) if what == "membership" else cat.loglike_per_star(row)
 
     def close(self):
         if self._catalog is not None:

@@ -158,8 +158,10 @@ struct mcd_catalog {
 namespace {
 
 int param_count(int model, bool free_centre) {
-    int k = 4 + (free_centre ? 2 : 0);
-    if (model == MCD_MODEL_CONST_BGGAUSS) k += 3;
+    int k = (mcd::is_profile(model) ? 6 : 4) + (free_centre ? 2 : 0);
+    const int bg = mcd::bg_kind(model);
+    if (bg == mcd::BG_GAUSS) k += 3;
+    if (bg == mcd::BG_FIXED_DENSITY) k += 1;
     return k;
 }
 
@@ -241,41 +243,63 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
 // expressions term by term.
 bool fast_guard(const mcd_catalog* cat, const double* params, int64_t n_rows) {
     if (!cat->allow_fast || cat->precision != MCD_F64) return false;
-    if (!cat->stats_finite) return false;
+    if (!cat->stats_finite || n_rows == 0) return false;
     const int k = cat->k;
-    double s2_min = std::numeric_limits<double>::infinity(), s2_max = 0.0, amp = 0.0;
-    double sb2_min = s2_min, sb2_max = 0.0, f_min = s2_min, f_max = 0.0;
+    const bool prof = mcd::is_profile(cat->model);
+    const int bg = mcd::bg_kind(cat->model);
+    const int ix = prof ? 3 : 2, iy = prof ? 4 : 3;
+    const double inf = std::numeric_limits<double>::infinity();
+    double s2_min = inf, s2_max = 0.0, amp = 0.0, sb2_min = inf, sb2_max = 0.0, f_min = inf, f_max = 0.0;
+    double len_min = inf, len_max = 0.0;                       // a and r_peak of the profile models
     for (int64_t i = 0; i < n_rows; ++i) {
         const double* p = params + i * k;
         const double s2 = p[1] * p[1];
-        double a = std::fabs(p[0]) + std::fabs(p[2]) + std::fabs(p[3]);
-        if (cat->model == MCD_MODEL_CONST_BGGAUSS) {
-            const double sb2 = p[k - 2] * p[k - 2], f = p[k - 1];
+        double a = std::fabs(p[0]) + std::fabs(p[ix]) + std::fabs(p[iy]);
+        if (prof) {
+            if (!(std::isfinite(p[2]) && std::isfinite(p[5]))) return false;
+            len_min = std::min(len_min, std::min(p[2], p[5]));
+            len_max = std::max(len_max, std::max(p[2], p[5]));
+        }
+        if (bg == mcd::BG_GAUSS) {
+            const double sb2 = p[k - 2] * p[k - 2];
             a = std::max(a, std::fabs(p[k - 3]));
-            if (!(std::isfinite(sb2) && std::isfinite(f))) return false;
+            if (!std::isfinite(sb2)) return false;
             sb2_min = std::min(sb2_min, sb2); sb2_max = std::max(sb2_max, sb2);
+        }
+        if (bg == mcd::BG_GAUSS || bg == mcd::BG_FIXED_DENSITY) {
+            const double f = p[k - 1];
+            if (!std::isfinite(f)) return false;
             f_min = std::min(f_min, f); f_max = std::max(f_max, f);
         }
-        if (cat->free_centre && !(std::isfinite(p[4]) && std::isfinite(p[5]))) return false;
+        if (cat->free_centre) {
+            const int ic = prof ? 6 : 4;
+            if (!(std::isfinite(p[ic]) && std::isfinite(p[ic + 1]))) return false;
+        }
         if (!(std::isfinite(s2) && std::isfinite(a))) return false;
         s2_min = std::min(s2_min, s2);
         s2_max = std::max(s2_max, s2);
         amp = std::max(amp, a);
     }
-    if (n_rows == 0) return false;
-    if (!(cat->v_abs_max + amp <= std::ldexp(1.0, 58))) return false;
-    if (cat->model == MCD_MODEL_CONST)
-        return (cat->e2_min + s2_min >= std::ldexp(1.0, -60)) && (cat->e2_max + s2_max <= std::ldexp(1.0, 60));
-    const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
-    if (!((cat->e2_min + s2_min >= lo) && (cat->e2_max + s2_max <= hi))) return false;
-    // exponent arguments stay below 1e9 in magnitude: (|v| + |v_los|)^2 / norm_min <= 1.6e9
+    // |v - v_los| <= |v| + |v_sys| + |v_max| (the Lynden-Bell factor 2 r r_peak / (r^2 + r_peak^2) is <= 1)
     const double d_max = cat->v_abs_max + amp;
-    if (!(d_max * d_max <= 1.6e9 * (cat->e2_min + s2_min))) return false;
-    if (cat->model == MCD_MODEL_CONST_BGFIXED) return cat->extras_ok;
-    if (!((cat->e2_min + sb2_min >= lo) && (cat->e2_max + sb2_max <= hi))) return false;
-    if (!(d_max * d_max <= 1.6e9 * (cat->e2_min + sb2_min))) return false;
-    return cat->extras_ok && f_min >= 0.0 && (cat->rho_min + f_min >= std::ldexp(1.0, -100)) &&
-           (cat->rho_max + f_max <= std::ldexp(1.0, 100));
+    if (!(d_max <= std::ldexp(1.0, 58))) return false;
+    // sigma_los of the profile models decays to 0 at large r: only verr^2 bounds the variance from below
+    const double n_min = cat->e2_min + (prof ? 0.0 : s2_min), n_max = cat->e2_max + s2_max;
+    if (prof && !(len_min >= std::ldexp(1.0, -100) && len_max <= std::ldexp(1.0, 100))) return false;   // a, r_peak > 0
+    if (bg == mcd::BG_NONE)
+        return (n_min >= std::ldexp(1.0, -60)) && (n_max <= std::ldexp(1.0, 60));
+    const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
+    if (!((n_min >= lo) && (n_max <= hi))) return false;
+    // exponent arguments stay below 1e9 in magnitude: (|v| + |v_los|)^2 / norm_min <= 1.6e9
+    if (!(d_max * d_max <= 1.6e9 * n_min)) return false;
+    if (!cat->extras_ok) return false;
+    if (bg == mcd::BG_GAUSS) {
+        if (!((cat->e2_min + sb2_min >= lo) && (cat->e2_max + sb2_max <= hi))) return false;
+        if (!(d_max * d_max <= 1.6e9 * (cat->e2_min + sb2_min))) return false;
+    }
+    if (bg == mcd::BG_GAUSS || bg == mcd::BG_FIXED_DENSITY)
+        return f_min >= 0.0 && (cat->rho_min + f_min >= std::ldexp(1.0, -100)) && (cat->rho_max + f_max <= std::ldexp(1.0, 100));
+    return true;
 }
 
 int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params) {
@@ -337,7 +361,9 @@ int enqueue(mcd_catalog* cat) {
         MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, W));
         if (cat->timing) MCD_HIP(hipEventRecord(k1, slot.stream));
         // the fast BGFIXED kernel leaves the walker-independent sum of lnL_bg to the reduction
-        const double* pset_const = (w.fast && cat->model == MCD_MODEL_CONST_BGFIXED) ? sh.d_pset_const : nullptr;
+        const int bgk = mcd::bg_kind(cat->model);
+        const double* pset_const =
+            (w.fast && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
         MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, w.n_chunks,
                                    w.max_chunks_per_pset, W, pset_const, w.d_out));
     }
@@ -512,16 +538,17 @@ int mcd_ctx_n_devices(const mcd_ctx* ctx) { return ctx ? (int)ctx->slots.size() 
 int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** out) {
     if (!ctx || !d || !out) return fail(MCD_ERR_INVALID, "mcd_catalog_create: null argument");
     if (d->n_stars < 0) return fail(MCD_ERR_INVALID, "negative n_stars");
-    if (d->model == MCD_MODEL_PROFILE || d->model == MCD_MODEL_PROFILE_BGGAUSS)
-        return fail(MCD_ERR_INVALID, "profile models are not part of ABI version 1");
-    if (d->model < 0 || d->model > MCD_MODEL_CONST_BGGAUSS) return fail(MCD_ERR_INVALID, "unknown model");
+    if (d->model < 0 || d->model > MCD_MODEL_PROFILE_BGDENS) return fail(MCD_ERR_INVALID, "unknown model");
+    const int bgk = mcd::bg_kind(d->model);
     if (d->centre != MCD_CENTRE_FIXED && d->centre != MCD_CENTRE_FREE) return fail(MCD_ERR_INVALID, "unknown centre mode");
     if (d->precision < MCD_F64 || d->precision > MCD_F32_ACC64) return fail(MCD_ERR_INVALID, "unknown precision");
     if (d->n_stars > 0 && (!d->ra || !d->dec || !d->v || !d->verr)) return fail(MCD_ERR_INVALID, "missing ra/dec/v/verr column");
-    if (d->model == MCD_MODEL_CONST_BGFIXED && d->n_stars > 0 && (!d->lnlike_bg || !d->pmember))
+    if (bgk == mcd::BG_FIXED && d->n_stars > 0 && (!d->lnlike_bg || !d->pmember))
         return fail(MCD_ERR_INVALID, "background model needs lnlike_bg and pmember columns");
-    if (d->model == MCD_MODEL_CONST_BGGAUSS && d->n_stars > 0 && !d->density)
+    if (bgk == mcd::BG_GAUSS && d->n_stars > 0 && !d->density)
         return fail(MCD_ERR_INVALID, "Gaussian-background model needs the density column");
+    if (bgk == mcd::BG_FIXED_DENSITY && d->n_stars > 0 && (!d->lnlike_bg || !d->density))
+        return fail(MCD_ERR_INVALID, "constant-background model needs lnlike_bg and density columns");
 
     std::unique_ptr<mcd_catalog> cat(new (std::nothrow) mcd_catalog());
     if (!cat) return fail(MCD_ERR_INVALID, "out of memory");
@@ -561,20 +588,23 @@ int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** ou
     }
     if (d->n_stars == 0) e2_min = 0.0;
     cat->e2_min = e2_min; cat->e2_max = e2_max; cat->v_abs_max = v_abs; cat->stats_finite = finite;
-    if (d->model == MCD_MODEL_CONST_BGFIXED) {
+    {
         bool ok = true;
-        for (int64_t i = 0; i < d->n_stars; ++i) {
-            const double b = d->lnlike_bg[i], pm = d->pmember[i];
-            if (!(std::isfinite(b) && b > -1.0e5 && b < 1.0e5 && pm >= 0.0 && pm <= 1.0)) { ok = false; break; }
-        }
-        cat->extras_ok = ok;
-    } else if (d->model == MCD_MODEL_CONST_BGGAUSS) {
         double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
-        bool ok = true;
-        for (int64_t i = 0; i < d->n_stars; ++i) {
-            const double rho = d->density[i];
-            if (!(std::isfinite(rho) && rho >= 0.0)) { ok = false; break; }
-            r_min = std::min(r_min, rho); r_max = std::max(r_max, rho);
+        for (int64_t i = 0; i < d->n_stars && ok; ++i) {
+            if (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY) {
+                const double b = d->lnlike_bg[i];
+                if (!(std::isfinite(b) && b > -1.0e5 && b < 1.0e5)) ok = false;
+            }
+            if (bgk == mcd::BG_FIXED) {
+                const double pm = d->pmember[i];
+                if (!(pm >= 0.0 && pm <= 1.0)) ok = false;
+            }
+            if (bgk == mcd::BG_GAUSS || bgk == mcd::BG_FIXED_DENSITY) {
+                const double rho = d->density[i];
+                if (!(std::isfinite(rho) && rho >= 0.0)) ok = false;
+                r_min = std::min(r_min, rho); r_max = std::max(r_max, rho);
+            }
         }
         if (d->n_stars == 0) r_min = 0.0;
         cat->extras_ok = ok; cat->rho_min = r_min; cat->rho_max = r_max;
@@ -597,7 +627,7 @@ int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** ou
         MCD_HIP(hipEventCreate(&sh.ev_end));
         MCD_HIP(hipMalloc(&sh.records, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256)));  // slack for wide scalar loads
         MCD_HIP(hipMemsetAsync(sh.records, 0, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256), slot.stream));
-        if (d->model == MCD_MODEL_CONST_BGFIXED) {
+        if (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY) {
             std::vector<double> sums(cat->n_psets, 0.0);
             for (int64_t p = 0; p < cat->n_psets; ++p) {
                 const int64_t b0 = std::max(cat->bin_offsets[p], sh.star_begin);
@@ -675,10 +705,11 @@ int mcd_loglike_batch(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
     return fetch(cat, out);
 }
 
-int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* out) {
-    if (!cat || !params || !out) return fail(MCD_ERR_INVALID, "mcd_membership: null argument");
-    if (cat->model != MCD_MODEL_CONST_BGGAUSS) return fail(MCD_ERR_INVALID, "membership needs a Gaussian-background catalogue");
-    if (cat->n_psets != 1) return fail(MCD_ERR_INVALID, "membership is defined for un-binned catalogues");
+namespace {
+int per_star(mcd_catalog* cat, int32_t k, const double* params, int mode, double* out) {
+    if (!cat || !params || !out) return fail(MCD_ERR_INVALID, "per-star output: null argument");
+    if (mcd::bg_kind(cat->model) == mcd::BG_NONE) return fail(MCD_ERR_INVALID, "per-star outputs need a background model");
+    if (cat->n_psets != 1) return fail(MCD_ERR_INVALID, "per-star outputs are defined for un-binned catalogues");
     if (k != cat->k) return fail(MCD_ERR_INVALID, "parameter row has the wrong number of columns");
     const size_t term_bytes = cat->precision == MCD_F64 ? 8 : 4;
     for (Shard& sh : cat->shards) {
@@ -692,12 +723,21 @@ int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* ou
         MCD_HIP(hipMemcpyAsync(d_p, params, k * sizeof(double), hipMemcpyHostToDevice, slot.stream));
         MCD_HIP(mcd::launch_prepare_walkers(slot.stream, d_p, 1, k, cat->model, cat->free_centre, cat->precision, d_w));
         mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, false};
-        MCD_HIP(mcd::launch_membership(slot.stream, shape, sh.records, sh.n, d_w, d_o));
+        MCD_HIP(mcd::launch_per_star(slot.stream, shape, sh.records, sh.n, d_w, mode, d_o));
         MCD_HIP(hipMemcpyAsync(out + sh.star_begin, d_o, (size_t)sh.n * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
         MCD_HIP(hipStreamSynchronize(slot.stream));
         MCD_HIP(hipFree(d_p)); MCD_HIP(hipFree(d_w)); MCD_HIP(hipFree(d_o));
     }
     return MCD_OK;
+}
+}  // namespace
+
+int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* out) {
+    return per_star(cat, k, params, 0, out);
+}
+
+int mcd_loglike_per_star(mcd_catalog* cat, int32_t k, const double* params, double* out) {
+    return per_star(cat, k, params, 1, out);
 }
 
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {

@@ -48,8 +48,9 @@ hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* p
                          int64_t n_psets, int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers,
                          const double* pset_const, double* out);
 
-hipError_t launch_membership(hipStream_t s, const LaunchShape& shape, const void* records, int64_t n,
-                             const void* wpar_row, double* out);
+// per-star outputs for one parameter row: mode 0 membership probability, mode 1 mixture log-likelihood
+hipError_t launch_per_star(hipStream_t s, const LaunchShape& shape, const void* records, int64_t n,
+                           const void* wpar_row, int mode, double* out);
 
 int record_bytes(int model, bool free_centre, int precision);
 

@@ -39,30 +39,41 @@ __global__ __launch_bounds__(kBlock) void prepare_records_kernel(RawColumns raw,
     r[0] = (T)raw.v[i];
     r[1] = (T)(verr * verr);                                        // runner.py:261 (verr * verr)
     const double ra = raw.ra[i], dec = raw.dec[i];
-    int k;
+    const int k = geometry_doubles(model, free_centre != 0);
     if (free_centre) {
         double sa, ca, sd, cd;
         sincos(ra * kDeg2Rad, &sa, &ca);
         sincos(dec * kDeg2Rad, &sd, &cd);
         r[2] = (T)sa; r[3] = (T)ca; r[4] = (T)sd; r[5] = (T)cd;
-        k = 6;
     } else {
-        // calc_xy_offset.py:30-31 followed by arctan2 (constant.py:107), reduced to sin/cos(theta)
+        // calc_xy_offset.py:30-31
         const double dra = (ra - ra_c) * kDeg2Rad;
         const double dec_r = dec * kDeg2Rad, dec_cr = dec_c * kDeg2Rad;
         const double dx = -kR0Arcmin * cos(dec_r) * sin(dra);
         const double dy = kR0Arcmin * (sin(dec_r) * cos(dec_cr) - cos(dec_r) * sin(dec_cr) * cos(dra));
-        const double rr = hypot(dx, dy);
-        double s, c;
-        if (rr > 0.0) { s = dy / rr; c = dx / rr; }
-        else { s = 0.0; c = signbit(dx) ? -1.0 : 1.0; }            // numpy arctan2(+0, -0) = pi
-        r[2] = (T)s; r[3] = (T)c;
-        k = 4;
+        if (is_profile(model)) {
+            // model.py:124-127, 171-180 use r, dx, dy themselves; arcsec because a and r_peak are in arcsec
+            const double xs = 60.0 * dx, ys = 60.0 * dy;
+            r[2] = (T)xs; r[3] = (T)ys; r[4] = (T)(xs * xs + ys * ys); r[5] = (T)0;
+        } else {
+            // followed by arctan2 (constant.py:107), reduced to sin/cos(theta)
+            const double rr = hypot(dx, dy);
+            double s, c;
+            if (rr > 0.0) { s = dy / rr; c = dx / rr; }
+            else { s = 0.0; c = signbit(dx) ? -1.0 : 1.0; }        // numpy arctan2(+0, -0) = pi
+            r[2] = (T)s; r[3] = (T)c;
+        }
     }
-    if (model == MODEL_BGFIXED) {
+    const int bg = bg_kind(model);
+    if (bg == BG_FIXED) {
         const double b = raw.lnbg[i], pm = raw.pmember[i];
         r[k] = (T)b; r[k + 1] = (T)pm; r[k + 2] = (T)(1.0 - pm); r[k + 3] = (T)(-(b + kHalfLn2Pi));
-    } else if (model == MODEL_BGGAUSS) { r[k] = (T)raw.density[i]; r[k + 1] = (T)0; }
+    } else if (bg == BG_GAUSS) {
+        r[k] = (T)raw.density[i]; r[k + 1] = (T)0;
+    } else if (bg == BG_FIXED_DENSITY) {
+        const double b = raw.lnbg[i];
+        r[k] = (T)b; r[k + 1] = (T)(-(b + kHalfLn2Pi)); r[k + 2] = (T)raw.density[i]; r[k + 3] = (T)0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -75,22 +86,30 @@ __global__ __launch_bounds__(kBlock) void prepare_walkers_kernel(const double* _
     if (i >= n_rows) return;
     const double* p = params + i * k;
     T* w = wpar + i * KD;
+    // CONST:   v_sys, sigma_max, v_maxx, v_maxy [, ra_c, dec_c] [, v_back, sigma_back, f_back]
+    // PROFILE: v_sys, sigma_max, a, v_maxx, v_maxy, r_peak [, ra_c, dec_c] [, v_back, sigma_back, f_back | f_back]
+    const bool prof = is_profile(model);
     const double sigma = p[1];
+    const double a = prof ? p[2] : 0.0, rp = prof ? p[5] : 0.0;
     w[W_VSYS] = (T)p[0];
     w[W_S2] = (T)(sigma * sigma);                                   // runner.py:261 (sigma_los * sigma_los)
-    w[W_VX] = (T)p[2];
-    w[W_VY] = (T)p[3];
-    int j = 4;
+    w[W_VX] = (T)(prof ? p[3] : p[2]);
+    w[W_VY] = (T)(prof ? p[4] : p[3]);
+    w[W_A2] = (T)(a * a); w[W_S2A] = (T)(sigma * sigma * a); w[W_RP2] = (T)(rp * rp); w[W_2RP] = (T)(2.0 * rp);
+    w[15] = (T)0;
+    int j = prof ? 6 : 4;
     double sac = 0, cac = 1, sdc = 0, cdc = 1;
     if (free_centre) {
-        sincos(p[4] * kDeg2Rad, &sac, &cac);
-        sincos(p[5] * kDeg2Rad, &sdc, &cdc);
-        j = 6;
+        sincos(p[j] * kDeg2Rad, &sac, &cac);
+        sincos(p[j + 1] * kDeg2Rad, &sdc, &cdc);
+        j += 2;
     }
     w[W_SAC] = (T)sac; w[W_CAC] = (T)cac; w[W_SDC] = (T)sdc; w[W_CDC] = (T)cdc;
     double vb = 0, sb = 0, fb = 0;
-    if (model == MODEL_BGGAUSS) { vb = p[j]; sb = p[j + 1]; fb = p[j + 2]; }
-    w[W_VB] = (T)vb; w[W_SB2] = (T)(sb * sb); w[W_FB] = (T)fb; w[W_LNF] = (T)0;
+    const int bg = bg_kind(model);
+    if (bg == BG_GAUSS) { vb = p[j]; sb = p[j + 1]; fb = p[j + 2]; }
+    else if (bg == BG_FIXED_DENSITY) { fb = p[j]; }
+    w[W_VB] = (T)vb; w[W_SB2] = (T)(sb * sb); w[W_FB] = (T)fb;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -115,9 +134,7 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
 
     const T* __restrict__ wp = wpar + ((int64_t)ch.pset * n_walkers + w_idx) * KD;
     WalkerConsts<T> w;
-    w.vsys = wp[W_VSYS]; w.s2 = wp[W_S2]; w.vx = wp[W_VX]; w.vy = wp[W_VY];
-    if (FREE) { w.sac = wp[W_SAC]; w.cac = wp[W_CAC]; w.sdc = wp[W_SDC]; w.cdc = wp[W_CDC]; }
-    if (MODEL == MODEL_BGGAUSS) { w.vb = wp[W_VB]; w.sb2 = wp[W_SB2]; w.fb = wp[W_FB]; }
+    w.load(wp);                                   // unused constants are dead code for a given MODEL
 
     // wave-uniform record pointer: the reads inside chunk_loglike become scalar loads
     const double result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w);
@@ -169,25 +186,24 @@ __global__ __launch_bounds__(kBlock) void reduce_narrow_kernel(const double* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// membership probabilities (constant.py:366-374): one thread per star, one parameter row
-template <bool FREE, class T>
-__global__ __launch_bounds__(kBlock) void membership_kernel(const T* __restrict__ recs, int64_t n,
-                                                             const T* __restrict__ wp, double* __restrict__ out) {
-    constexpr int ND = record_doubles(MODEL_BGGAUSS, FREE);
+// per-star outputs for ONE parameter row (one thread per star):
+//   mode 0: membership probability  m e^{lc} / (m e^{lc} + (1 - m) e^{lb})   (constant.py:366-374; the ModelFit
+//           classes subtract max(lc, lb) first, model.py:505-510, 680-687)
+//   mode 1: per-star log-likelihood of the mixture, `lnlike(no_sum=True)` of model.py:565-623
+template <int MODEL, bool FREE, class T>
+__global__ __launch_bounds__(kBlock) void per_star_kernel(const T* __restrict__ recs, int64_t n,
+                                                           const T* __restrict__ wp, int mode,
+                                                           double* __restrict__ out) {
+    constexpr int ND = record_doubles(MODEL, FREE);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     WalkerConsts<T> w;
-    w.vsys = wp[W_VSYS]; w.s2 = wp[W_S2]; w.vx = wp[W_VX]; w.vy = wp[W_VY];
-    w.sac = wp[W_SAC]; w.cac = wp[W_CAC]; w.sdc = wp[W_SDC]; w.cdc = wp[W_CDC];
-    w.vb = wp[W_VB]; w.sb2 = wp[W_SB2]; w.fb = wp[W_FB];
-    const T* r = recs + i * ND;
-    T d, nrm;
-    star_d_n<T, FREE>(r, w, d, nrm);
-    const T lc = gauss_lnl(d, nrm);
-    const T lb = gauss_lnl(r[0] - w.vb, r[1] + w.sb2);
-    const T rho = r[FREE ? 6 : 4];
-    const T m = rho / (rho + w.fb);
-    const T ec = m * exp_(lc), eb = (T(1) - m) * exp_(lb);
+    w.load(wp);
+    T lc, lb, m;
+    star_components<MODEL, FREE, T>(recs + i * ND, w, lc, lb, m);
+    if (mode == 1) { out[i] = (double)mixture_lnl(lc, lb, m); return; }
+    const T shift = is_profile(MODEL) ? max_(lc, lb) : T(0);
+    const T ec = m * exp_(lc - shift), eb = (T(1) - m) * exp_(lb - shift);
     out[i] = (double)(ec / (ec + eb));
 }
 
@@ -262,6 +278,9 @@ hipError_t launch_loglike(hipStream_t s, const LaunchShape& sh, const void* reco
         MCD_DISPATCH(MODEL_CONST)
         MCD_DISPATCH(MODEL_BGFIXED)
         MCD_DISPATCH(MODEL_BGGAUSS)
+        MCD_DISPATCH(MODEL_PROFILE)
+        MCD_DISPATCH(MODEL_PROFILE_BGGAUSS)
+        MCD_DISPATCH(MODEL_PROFILE_BGDENS)
     }
 #undef MCD_DISPATCH
     return hipErrorInvalidValue;
@@ -283,26 +302,40 @@ hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* o
     return hipGetLastError();
 }
 
-hipError_t launch_membership(hipStream_t s, const LaunchShape& sh, const void* records, int64_t n,
-                             const void* wpar_row, double* out) {
-    if (n <= 0) return hipSuccess;
+namespace {
+template <int MODEL>
+hipError_t per_star_model(hipStream_t s, const LaunchShape& sh, const void* records, int64_t n, const void* wpar_row,
+                          int mode, double* out) {
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
     if (sh.precision == 0) {
         if (sh.free_centre)
-            hipLaunchKernelGGL((membership_kernel<true, double>), dim3(grid), dim3(kBlock), 0, s,
-                               (const double*)records, n, (const double*)wpar_row, out);
+            hipLaunchKernelGGL((per_star_kernel<MODEL, true, double>), dim3(grid), dim3(kBlock), 0, s,
+                               (const double*)records, n, (const double*)wpar_row, mode, out);
         else
-            hipLaunchKernelGGL((membership_kernel<false, double>), dim3(grid), dim3(kBlock), 0, s,
-                               (const double*)records, n, (const double*)wpar_row, out);
+            hipLaunchKernelGGL((per_star_kernel<MODEL, false, double>), dim3(grid), dim3(kBlock), 0, s,
+                               (const double*)records, n, (const double*)wpar_row, mode, out);
     } else {
         if (sh.free_centre)
-            hipLaunchKernelGGL((membership_kernel<true, float>), dim3(grid), dim3(kBlock), 0, s,
-                               (const float*)records, n, (const float*)wpar_row, out);
+            hipLaunchKernelGGL((per_star_kernel<MODEL, true, float>), dim3(grid), dim3(kBlock), 0, s,
+                               (const float*)records, n, (const float*)wpar_row, mode, out);
         else
-            hipLaunchKernelGGL((membership_kernel<false, float>), dim3(grid), dim3(kBlock), 0, s,
-                               (const float*)records, n, (const float*)wpar_row, out);
+            hipLaunchKernelGGL((per_star_kernel<MODEL, false, float>), dim3(grid), dim3(kBlock), 0, s,
+                               (const float*)records, n, (const float*)wpar_row, mode, out);
     }
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_per_star(hipStream_t s, const LaunchShape& sh, const void* records, int64_t n,
+                           const void* wpar_row, int mode, double* out) {
+    if (n <= 0) return hipSuccess;
+    switch (sh.model) {
+        case MODEL_BGFIXED: return per_star_model<MODEL_BGFIXED>(s, sh, records, n, wpar_row, mode, out);
+        case MODEL_BGGAUSS: return per_star_model<MODEL_BGGAUSS>(s, sh, records, n, wpar_row, mode, out);
+        case MODEL_PROFILE_BGGAUSS: return per_star_model<MODEL_PROFILE_BGGAUSS>(s, sh, records, n, wpar_row, mode, out);
+        case MODEL_PROFILE_BGDENS: return per_star_model<MODEL_PROFILE_BGDENS>(s, sh, records, n, wpar_row, mode, out);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace mcd

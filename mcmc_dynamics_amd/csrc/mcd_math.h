@@ -33,18 +33,43 @@ constexpr double kHalfLn2Pi = 0.918938533204672741780329736406;
 enum WalkerSlot : int {
     W_VSYS = 0, W_S2 = 1, W_VX = 2, W_VY = 3,       // v_sys, sigma_max^2, v_maxx, v_maxy
     W_SAC = 4, W_CAC = 5, W_SDC = 6, W_CDC = 7,     // sin/cos(ra_center), sin/cos(dec_center)
-    W_VB = 8, W_SB2 = 9, W_FB = 10, W_LNF = 11,     // v_back, sigma_back^2, f_back, (spare)
-    KD = 12
+    W_VB = 8, W_SB2 = 9, W_FB = 10,                 // v_back, sigma_back^2, f_back
+    W_A2 = 11, W_S2A = 12, W_RP2 = 13, W_2RP = 14,  // profile models: a^2, sigma_max^2 a, r_peak^2, 2 r_peak (arcsec)
+    KD = 16
 };
 
-// Star record slots (doubles).  Fixed centre: v, e2, sin(theta), cos(theta), extras.
-// Free centre: v, e2, sin(ra), cos(ra), sin(dec), cos(dec), extras.
-// extras: BGFIXED -> lnlike_bg, pmember, 1 - pmember, -(lnlike_bg + 1/2 log 2pi) ; BGGAUSS -> density, (pad)
-enum Model : int { MODEL_CONST = 0, MODEL_BGFIXED = 1, MODEL_BGGAUSS = 2 };
+// Likelihood variants.  Cluster part: CONST (analysis/constant.py) or PROFILE (analysis/model.py:93-180);
+// background part: none, fixed per-star lnL + pmember (runner.py:272-286), per-walker Gaussian + density prior
+// (constant.py:326-364, model.py:391-456), fixed per-star lnL + density prior with per-walker f_back (model.py:565-623).
+enum Model : int {
+    MODEL_CONST = 0, MODEL_BGFIXED = 1, MODEL_BGGAUSS = 2,
+    MODEL_PROFILE = 3, MODEL_PROFILE_BGGAUSS = 4, MODEL_PROFILE_BGDENS = 5
+};
+enum Background : int { BG_NONE = 0, BG_FIXED = 1, BG_GAUSS = 2, BG_FIXED_DENSITY = 3 };
 
-MCD_HD constexpr int record_doubles(int model, bool free_centre) {
-    return (free_centre ? 6 : 4) + (model == MODEL_CONST ? 0 : (model == MODEL_BGFIXED ? 4 : 2));
+MCD_HD constexpr bool is_profile(int model) { return model >= MODEL_PROFILE; }
+MCD_HD constexpr int bg_kind(int model) {
+    return (model == MODEL_CONST || model == MODEL_PROFILE) ? BG_NONE
+           : (model == MODEL_BGFIXED) ? BG_FIXED
+           : (model == MODEL_PROFILE_BGDENS) ? BG_FIXED_DENSITY : BG_GAUSS;
 }
+
+// Star record slots (doubles).
+//   CONST,   fixed centre: v, e2, sin(theta), cos(theta)                     (4)
+//   PROFILE, fixed centre: v, e2, dx, dy [arcsec], r^2 [arcsec^2], pad       (6)
+//   free centre (both)   : v, e2, sin(ra), cos(ra), sin(dec), cos(dec)       (6)
+// extras: BG_FIXED -> lnL_bg, pmember, 1 - pmember, -(lnL_bg + 1/2 log 2pi)   (4)
+//         BG_GAUSS -> density, pad                                            (2)
+//         BG_FIXED_DENSITY -> lnL_bg, -(lnL_bg + 1/2 log 2pi), density, pad   (4)
+MCD_HD constexpr int geometry_doubles(int model, bool free_centre) {
+    return (free_centre || is_profile(model)) ? 6 : 4;
+}
+MCD_HD constexpr int record_doubles(int model, bool free_centre) {
+    return geometry_doubles(model, free_centre) +
+           (bg_kind(model) == BG_NONE ? 0 : (bg_kind(model) == BG_GAUSS ? 2 : 4));
+}
+
+constexpr double kArcsecPerRad = 206264.80624709635516;   // 10800 / pi arcmin x 60: r0 of calc_xy_offset.py:11 in arcsec
 
 template <class T>
 MCD_HD T fma_(T a, T b, T c) {
@@ -67,12 +92,23 @@ MCD_HD float fma_(float a, float b, float c) {
 // arctan2, constant.py:106-107; the r0 factor cancels).  r == 0 follows numpy's arctan2(+0, -0) = pi.
 MCD_HD double rsqrt_nr(double n);
 
-template <bool FASTMATH, class T>
-MCD_HD void free_centre_geometry(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T cdc, T& s, T& c) {
+// Tangent-plane offsets (x, y) of a star about a walker's centre in units of r0 (radians of the orthographic
+// projection), from the sines/cosines of the star's and the centre's coordinates: the angle-addition form of
+// calc_xy_offset.py:30-31.
+template <class T>
+MCD_HD void free_centre_xy(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T cdc, T& x, T& y) {
     T sin_dra = fma_(sa, cac, -(ca * sac));
     T cos_dra = fma_(ca, cac, sa * sac);
-    T x = -(cd * sin_dra);
-    T y = fma_(sd, cdc, -(cd * sdc * cos_dra));
+    x = -(cd * sin_dra);
+    y = fma_(sd, cdc, -(cd * sdc * cos_dra));
+}
+
+// sin(theta), cos(theta) of the position angle theta = arctan2(y, x) (constant.py:106-107; the r0 factor cancels).
+// r == 0 follows numpy's arctan2(+0, -0) = pi.
+template <bool FASTMATH, class T>
+MCD_HD void free_centre_geometry(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T cdc, T& s, T& c) {
+    T x, y;
+    free_centre_xy(sa, ca, sd, cd, sac, cac, sdc, cdc, x, y);
     T r2 = fma_(x, x, y * y);
     if (r2 > T(0)) {
         T inv;
@@ -223,6 +259,17 @@ MCD_HD double rsqrt_nr(double n) {
     return fma_(y, t * e, y);
 }
 
+MCD_HD double rcp_nr(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);      // v_rcp_f64: measured max rel. error 2^-24.4 on gfx950
+#else
+    double y = 1.0 / x;
+#endif
+    // 1/x = y (1 + e + e^2 + O(e^3)),  e = 1 - x y
+    const double e = fma_(-x, y, 1.0);
+    return fma_(y, fma_(e, e, e), y);
+}
+
 // e^u = 2^k e^r with k = rint(u / ln 2), |r| <= ln2 / 2; returns the mantissa part e^r and k.
 // Polynomial: Taylor series to r^13 Chebyshev-economised to degree 11 on [-0.35, 0.35] (exact rational
 // arithmetic, then rounded to f64): approximation error 1.1e-17, 1.3e-16 with f64 Horner rounding.
@@ -270,9 +317,15 @@ MCD_HD double fmax_(double a, double b) {
 
 // MODEL_BGFIXED: lnL_i = b_i + log((1 - p_i) + p_i t_i),  t_i = exp(m_i - b_i) = g exp(-1/2 q g^2 - b'_i),
 // b'_i = b_i + 1/2 log 2pi  (the record carries nbp = -b'_i).  Same value as runner.py:280-286.
+// BG_FIXED_DENSITY (model.py:565-623) is the same with p -> rho_i, (1 - p) -> f_back and an extra -log(rho_i + f_back).
 struct BgFixedAcc {
     LogProduct l;          // sum log y_i   (sum b_i is walker-independent: added once per parameter set by the reduce kernel)
-    MCD_HD void init() { l.init(); }
+    LogProduct lden;       // BG_FIXED_DENSITY: sum log(rho_i + f)
+    MCD_HD void init() { l.init(); lden.init(); }
+    MCD_HD void add_density(double d, double n, double rho, double f, double nbp) {
+        add(d, n, rho, f, nbp);
+        lden.mul(rho + f);
+    }
     MCD_HD void add(double d, double n, double p, double omp, double nbp) {
         const double g = rsqrt_nr(n);
         const double dg = d * g;
@@ -291,7 +344,9 @@ struct BgFixedAcc {
         l.e32 += k - kc;
     }
     MCD_HD void rescale() { l.rescale(); }
+    MCD_HD void rescale_density() { l.rescale(); lden.rescale(); }
     MCD_HD double finish() { return l.value(); }
+    MCD_HD double finish_density() { return l.value() - lden.value(); }
 };
 
 // MODEL_BGGAUSS (constant.py:320-364):
@@ -331,25 +386,67 @@ struct BgGaussAcc {
 // One chunk of stars for one walker.  On the GPU `r` is wave-uniform (lane = walker), so every record
 // read below is a scalar load and the record values are SGPR operands of the vector ops.
 template <class T> struct WalkerConsts {
-    T vsys, s2, vx, vy, sac, cac, sdc, cdc, vb, sb2, fb;
+    T vsys, s2, vx, vy, sac, cac, sdc, cdc, vb, sb2, fb, a2, s2a, rp2, rp_2;
+    template <class P>
+    MCD_HD void load(const P* __restrict__ p) {
+        vsys = p[W_VSYS]; s2 = p[W_S2]; vx = p[W_VX]; vy = p[W_VY];
+        sac = p[W_SAC]; cac = p[W_CAC]; sdc = p[W_SDC]; cdc = p[W_CDC];
+        vb = p[W_VB]; sb2 = p[W_SB2]; fb = p[W_FB];
+        a2 = p[W_A2]; s2a = p[W_S2A]; rp2 = p[W_RP2]; rp_2 = p[W_2RP];
+    }
 };
 
-template <class T, bool FREE, bool FASTMATH = false>
+template <class T> MCD_HD T sqrt_(T x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return sqrt(x);
+#else
+    return std::sqrt(x);
+#endif
+}
+
+// Residual d = v - v_los and variance n = verr^2 + sigma_los^2 of one star for one walker.
+//   CONST   (constant.py:52-111): v_los = v_sys + v_maxx sin(theta) - v_maxy cos(theta), sigma_los = sigma_max
+//   PROFILE (model.py:93-180):    v_los = v_sys + 2 r_peak (v_maxx dy - v_maxy dx) / (r_peak^2 + r^2)
+//                                 sigma_los^2 = sigma_max^2 a / sqrt(a^2 + r^2)           (all lengths in arcsec)
+template <int MODEL, class T, bool FREE, bool FASTMATH = false>
 MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T& n) {
-    T s, c;
-    if (FREE) free_centre_geometry<FASTMATH>(r[2], r[3], r[4], r[5], w.sac, w.cac, w.sdc, w.cdc, s, c);
-    else { s = r[2]; c = r[3]; }
-    // v - (v_sys + v_maxx sin(theta) - v_maxy cos(theta))
-    d = fma_(-w.vx, s, fma_(w.vy, c, r[0] - w.vsys));
-    n = r[1] + w.s2;
+    if constexpr (!is_profile(MODEL)) {
+        T s, c;
+        if (FREE) free_centre_geometry<FASTMATH>(r[2], r[3], r[4], r[5], w.sac, w.cac, w.sdc, w.cdc, s, c);
+        else { s = r[2]; c = r[3]; }
+        d = fma_(-w.vx, s, fma_(w.vy, c, r[0] - w.vsys));
+        n = r[1] + w.s2;
+    } else {
+        T dx, dy, r2;
+        if (FREE) {
+            T x, y;
+            free_centre_xy(r[2], r[3], r[4], r[5], w.sac, w.cac, w.sdc, w.cdc, x, y);
+            dx = T(kArcsecPerRad) * x;
+            dy = T(kArcsecPerRad) * y;
+            r2 = fma_(dx, dx, dy * dy);
+        } else { dx = r[2]; dy = r[3]; r2 = r[4]; }
+        T t, inv;
+        if constexpr (FASTMATH && sizeof(T) == 8) {
+            t = (T)rsqrt_nr((double)(w.a2 + r2));
+            inv = (T)rcp_nr((double)(w.rp2 + r2));
+        } else {
+            t = T(1) / sqrt_(w.a2 + r2);
+            inv = T(1) / (w.rp2 + r2);
+        }
+        const T cross = fma_(w.vx, dy, -(w.vy * dx));
+        d = fma_(-(w.rp_2 * inv), cross, r[0] - w.vsys);
+        n = fma_(w.s2a, t, r[1]);
+    }
 }
 
 template <int MODEL, bool FREE, class T, class A, bool FAST>
 MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w) {
     constexpr int ND = record_doubles(MODEL, FREE);
+    constexpr int XB = geometry_doubles(MODEL, FREE);      // first background slot of a record
+    constexpr int BG = bg_kind(MODEL);
     double result;
 
-    if constexpr (MODEL == MODEL_CONST && FAST) {
+    if constexpr (BG == BG_NONE && FAST) {
         // fraction-tree + log-product path (f64 only): 8 stars -> one division, one product factor
         ConstAcc acc;
         acc.init();
@@ -359,30 +456,29 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 double d;
-                star_d_n<double, FREE, true>(r + j * ND, w, d, nn[j]);
+                star_d_n<MODEL, double, FREE, true>(r + j * ND, w, d, nn[j]);
                 qq[j] = d * d;
             }
             acc.add8(qq, nn);
         }
         for (int j = n8 * 8; j < count; ++j, r += ND) {
             double d, n;
-            star_d_n<double, FREE, true>(r, w, d, n);
+            star_d_n<MODEL, double, FREE, true>(r, w, d, n);
             acc.add1(d * d, n);
         }
         result = acc.finish(count);
-    } else if constexpr (MODEL == MODEL_CONST) {
+    } else if constexpr (BG == BG_NONE) {
         // plain path: one log and one division per term (runner.py:269-270 keeps two sums as well)
         A sum_log = 0, sum_q = 0;
 #pragma unroll 4
         for (int j = 0; j < count; ++j, r += ND) {
             T d, n;
-            star_d_n<T, FREE>(r, w, d, n);
+            star_d_n<MODEL, T, FREE>(r, w, d, n);
             sum_log += (A)log_(n);
             sum_q += (A)(d * d / n);
         }
         result = -0.5 * ((double)count * kLn2Pi + (double)sum_log + (double)sum_q);
-    } else if constexpr (MODEL == MODEL_BGFIXED && FAST) {
-        constexpr int XB = FREE ? 6 : 4;
+    } else if constexpr (BG == BG_FIXED && FAST) {
         BgFixedAcc acc;
         acc.init();
         const int n4 = count >> 2;
@@ -391,20 +487,40 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             for (int j = 0; j < 4; ++j) {
                 const double* rr = r + j * ND;
                 double d, n;
-                star_d_n<double, FREE, true>(rr, w, d, n);
+                star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
                 acc.add(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3]);
             }
             acc.rescale();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
-            star_d_n<double, FREE, true>(r, w, d, n);
+            star_d_n<MODEL, double, FREE, true>(r, w, d, n);
             acc.add(d, n, r[XB + 1], r[XB + 2], r[XB + 3]);
             acc.rescale();
         }
         result = acc.finish();
-    } else if constexpr (MODEL == MODEL_BGGAUSS && FAST) {
-        constexpr int XB = FREE ? 6 : 4;
+    } else if constexpr (BG == BG_FIXED_DENSITY && FAST) {
+        BgFixedAcc acc;
+        acc.init();
+        const int n4 = count >> 2;
+        for (int g = 0; g < n4; ++g, r += 4 * ND) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double* rr = r + j * ND;
+                double d, n;
+                star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
+                acc.add_density(d, n, rr[XB + 2], w.fb, rr[XB + 1]);
+            }
+            acc.rescale_density();
+        }
+        for (int j = n4 * 4; j < count; ++j, r += ND) {
+            double d, n;
+            star_d_n<MODEL, double, FREE, true>(r, w, d, n);
+            acc.add_density(d, n, r[XB + 2], w.fb, r[XB + 1]);
+            acc.rescale_density();
+        }
+        result = acc.finish_density();
+    } else if constexpr (BG == BG_GAUSS && FAST) {
         BgGaussAcc acc;
         acc.init();
         const int n4 = count >> 2;
@@ -413,42 +529,59 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             for (int j = 0; j < 4; ++j) {
                 const double* rr = r + j * ND;
                 double d, n;
-                star_d_n<double, FREE, true>(rr, w, d, n);
+                star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
                 acc.add(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb);
             }
             acc.rescale();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
-            star_d_n<double, FREE, true>(r, w, d, n);
+            star_d_n<MODEL, double, FREE, true>(r, w, d, n);
             acc.add(d, n, r[0] - w.vb, r[1] + w.sb2, r[XB], w.fb);
             acc.rescale();
         }
         result = acc.finish(count);
     } else {
-        constexpr int XB = FREE ? 6 : 4;
         A sum = 0;
 #pragma unroll 2
         for (int j = 0; j < count; ++j, r += ND) {
             T d, n;
-            star_d_n<T, FREE>(r, w, d, n);
+            star_d_n<MODEL, T, FREE>(r, w, d, n);
             const T m = gauss_lnl(d, n);
             T b, p;
-            if (MODEL == MODEL_BGFIXED) {
+            if (BG == BG_FIXED) {
                 b = r[XB];
                 p = r[XB + 1];
+            } else if (BG == BG_FIXED_DENSITY) {
+                b = r[XB];
+                const T rho = r[XB + 2];
+                p = rho / (rho + w.fb);                          // model.py:588
             } else {
-                const T nb = r[1] + w.sb2;                       // constant.py:333
+                const T nb = r[1] + w.sb2;                       // constant.py:333, model.py:423
                 const T db = r[0] - w.vb;
                 b = gauss_lnl(db, nb);                           // constant.py:334-336
                 const T rho = r[XB];
-                p = rho / (rho + w.fb);                          // constant.py:339
+                p = rho / (rho + w.fb);                          // constant.py:339, model.py:429
             }
             sum += (A)mixture_lnl(m, b, p);                      // runner.py:282-284, constant.py:320-323
         }
         result = (double)sum;
     }
     return result;
+}
+
+// Per-star log-likelihood pieces for the membership / no_sum outputs: cluster lnL, background lnL, prior m.
+template <int MODEL, bool FREE, class T>
+MCD_HD void star_components(const T* __restrict__ r, const WalkerConsts<T>& w, T& lc, T& lb, T& m) {
+    constexpr int XB = geometry_doubles(MODEL, FREE);
+    constexpr int BG = bg_kind(MODEL);
+    T d, n;
+    star_d_n<MODEL, T, FREE>(r, w, d, n);
+    lc = gauss_lnl(d, n);
+    if (BG == BG_FIXED) { lb = r[XB]; m = r[XB + 1]; }
+    else if (BG == BG_FIXED_DENSITY) { lb = r[XB]; const T rho = r[XB + 2]; m = rho / (rho + w.fb); }
+    else if (BG == BG_GAUSS) { lb = gauss_lnl(r[0] - w.vb, r[1] + w.sb2); const T rho = r[XB]; m = rho / (rho + w.fb); }
+    else { lb = T(-INFINITY); m = T(1); }
 }
 
 }  // namespace mcd

@@ -114,6 +114,66 @@ def gb_membership_probabilities(cat, *params):
     return m * np.exp(lc) / (m * np.exp(lc) + (1. - m) * np.exp(lb))
 
 
+# ---- ModelFit family (analysis/model.py): Lynden-Bell rotation curve + Plummer dispersion profile --------------
+# astropy keeps r in arcmin and a, r_peak in arcsec; the composite units are reduced when a dimensionless number is
+# added (x 3600 for arcmin^2/arcsec^2) or when the velocity is added to v_sys (x 60 for arcmin/arcsec).
+def model_dispersion(ra, dec, sigma_max, a, ra_center, dec_center):
+    """ModelFit.dispersion_model, analysis/model.py:93-127 (a in arcsec)."""
+    dx, dy = calc_xy_offset(ra, dec, ra_center, dec_center)
+    r = np.sqrt(dx ** 2 + dy ** 2)
+    return sigma_max / (1. + (r ** 2 / a ** 2) * 3600.0) ** 0.25                  # :127
+
+
+def model_rotation(ra, dec, v_sys, v_maxx, v_maxy, r_peak, ra_center, dec_center):
+    """ModelFit.rotation_model, analysis/model.py:129-180 (r_peak in arcsec)."""
+    dx, dy = calc_xy_offset(ra, dec, ra_center, dec_center)
+    r = np.sqrt(dx ** 2 + dy ** 2)
+    v_max = np.sqrt(v_maxx ** 2 + v_maxy ** 2)
+    theta_0 = np.arctan2(v_maxy, v_maxx)
+    theta = np.arctan2(dy, dx)
+    x_pa = r * np.sin(theta - theta_0)
+    return v_sys + (2. * (v_max / r_peak) * x_pa / (1. + ((r / r_peak) ** 2) * 3600.0)) * 60.0     # :180
+
+
+def faithful_model_lnlike(cat, v_sys, sigma_max, a, v_maxx, v_maxy, r_peak, ra_center, dec_center,
+                          lnlike_background=None, prior=None):
+    """ModelFit.lnlike (model.py:182-222); with ``lnlike_background`` and the membership prior ``prior`` also
+    ModelFitGB.lnlike (:391-456) and ModelFitConstantBackground.lnlike (:565-623)."""
+    v_los = model_rotation(cat["ra"], cat["dec"], v_sys, v_maxx, v_maxy, r_peak, ra_center, dec_center)
+    sigma_los = model_dispersion(cat["ra"], cat["dec"], sigma_max, a, ra_center, dec_center)
+    return calculate_lnlike(cat["v"], cat["verr"], v_los, sigma_los, lnlike_background, prior)
+
+
+def faithful_model_gb_lnlike(cat, v_sys, sigma_max, a, v_maxx, v_maxy, r_peak, ra_center, dec_center,
+                             v_back, sigma_back, f_back):
+    """ModelFitGB.lnlike, analysis/model.py:391-456."""
+    lnlike_back = gaussian_background(cat["v"], cat["verr"], v_back, sigma_back)      # :423-426
+    m = cat["density"] / (cat["density"] + f_back)                                  # :429
+    return faithful_model_lnlike(cat, v_sys, sigma_max, a, v_maxx, v_maxy, r_peak, ra_center, dec_center,
+                                 lnlike_back, m)
+
+
+def faithful_model_cb_lnlike(cat, v_sys, sigma_max, a, v_maxx, v_maxy, r_peak, ra_center, dec_center, f_back,
+                             lnlike_background, no_sum=False):
+    """ModelFitConstantBackground.lnlike, analysis/model.py:565-623 (fixed background, density prior)."""
+    m = cat["density"] / (cat["density"] + f_back)                                  # :588
+    if not no_sum:
+        return faithful_model_lnlike(cat, v_sys, sigma_max, a, v_maxx, v_maxy, r_peak, ra_center, dec_center,
+                                     lnlike_background, m)
+    v_los = model_rotation(cat["ra"], cat["dec"], v_sys, v_maxx, v_maxy, r_peak, ra_center, dec_center)
+    sigma_los = model_dispersion(cat["ra"], cat["dec"], sigma_max, a, ra_center, dec_center)
+    norm = cat["verr"] * cat["verr"] + sigma_los * sigma_los
+    lc = -0.5 * np.log(2. * np.pi * norm) - 0.5 * np.power(cat["v"] - v_los, 2) / norm
+    mx = np.max([lc, lnlike_background], axis=0)
+    return mx + np.log(m * np.exp(lc - mx) + (1. - m) * np.exp(lnlike_background - mx))
+
+
+def model_membership(cat, lnlike_cluster, lnlike_back, m):
+    """calculate_membership_probabilities of the ModelFit classes (model.py:505-510, 680-687): with the max subtracted."""
+    mx = np.max([lnlike_cluster, lnlike_back], axis=0)
+    return m * np.exp(lnlike_cluster - mx) / (m * np.exp(lnlike_cluster - mx) + (1. - m) * np.exp(lnlike_back - mx))
+
+
 def bounds_lnprior(values, lo, hi):
     """Runner.lnprior + Parameter.evaluate_lnprior (runner.py:182-217, parameter.py:684-705):
     0 inside the INCLUSIVE bounds, -inf outside; evaluated over every parameter, fixed ones too."""

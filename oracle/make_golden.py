@@ -28,7 +28,8 @@ numpy.alen = len
 import numpy as np                      # noqa: E402
 from astropy import units as u          # noqa: E402
 
-from mcmc_dynamics.analysis import ConstantFit, ConstantFitGB, ModelFit   # noqa: E402
+from mcmc_dynamics.analysis import (ConstantFit, ConstantFitGB, ModelFit, ModelFitGB,   # noqa: E402
+                                    ModelFitConstantBackground)
 from mcmc_dynamics.background import Gaussian                              # noqa: E402
 from mcmc_dynamics.utils.files import DataReader                           # noqa: E402
 
@@ -222,6 +223,59 @@ def main():
         save("model_fit" + ("_free" if free else "_fixed"),
              ra=cat["ra"], dec=cat["dec"], v=cat["v"], verr=cat["verr"],
              ra_center=ra_c, dec_center=dec_c, names=names, values=pos, lnprob=lnprobs(mf, pos))
+
+    # ---------------------------------------------------------------- ModelFitGB / ModelFitConstantBackground
+    def model_walkers(names, truth, n, seed):
+        rng = np.random.default_rng(seed)
+        pos = np.empty((n, len(names)))
+        for j, nme in enumerate(names):
+            t = truth[nme]
+            g = rng.normal(size=n)
+            if nme in ("ra_center", "dec_center"):
+                pos[:, j] = t + (0.05 / 60.0) * g
+            elif t == 0.0:
+                pos[:, j] = 0.5 * g
+            else:
+                pos[:, j] = t * (1.0 + 0.05 * g)
+        if "f_back" in names:
+            pos[:, names.index("f_back")] = np.clip(pos[:, names.index("f_back")], 0.0, 1.0)
+            pos[-2, names.index("f_back")] = 0.0
+            pos[-3, names.index("f_back")] = 1.2          # rejected
+        pos[-1, names.index("r_peak")] = -5.0             # rejected
+        return pos
+
+    truth_b = dict(catb["truth"], a=30.0, r_peak=60.0)
+    for free in (False, True):
+        mg = ModelFitGB(reader(catb, extra=("density",)))
+        if free:
+            mg.parameters["ra_center"].set(value=ra_c * u.deg)
+            mg.parameters["dec_center"].set(value=dec_c * u.deg)
+        else:
+            fix_center(mg, ra_c, dec_c)
+        names = list(mg.fitted_parameters)
+        pos = model_walkers(names, truth_b, 16, 21)
+        save("model_fit_gb" + ("_free" if free else "_fixed"),
+             ra=catb["ra"], dec=catb["dec"], v=catb["v"], verr=catb["verr"], density=catb["density"],
+             ra_center=ra_c, dec_center=dec_c, names=names, values=pos, lnprob=lnprobs(mg, pos), lnprior=lnpriors(mg, pos))
+
+        from mcmc_dynamics.parameter import Parameters
+        pars = Parameters().load(ModelFitConstantBackground.parameters_file)
+        del pars["v_back"]
+        del pars["sigma_back"]
+        mc = ModelFitConstantBackground(reader(catb, extra=("density",)), background=bg, parameters=pars)
+        if free:
+            mc.parameters["ra_center"].set(value=ra_c * u.deg)
+            mc.parameters["dec_center"].set(value=dec_c * u.deg)
+        else:
+            fix_center(mc, ra_c, dec_c)
+        names = list(mc.fitted_parameters)
+        pos = model_walkers(names, truth_b, 16, 22)
+        per_star = np.asarray(getattr(mc.lnlike(pos[1], no_sum=True), "value", mc.lnlike(pos[1], no_sum=True)), dtype=np.float64)
+        save("model_fit_cb" + ("_free" if free else "_fixed"),
+             ra=catb["ra"], dec=catb["dec"], v=catb["v"], verr=catb["verr"], density=catb["density"],
+             bg_mean=20.0, bg_sigma=40.0, lnlike_background=np.asarray(mc.lnlike_background, dtype=np.float64),
+             ra_center=ra_c, dec_center=dec_c, names=names, values=pos, lnprob=lnprobs(mc, pos), lnprior=lnpriors(mc, pos),
+             no_sum_row=1, lnlike_no_sum=per_star)
 
     # ---------------------------------------------------------------- interpreter record
     import astropy

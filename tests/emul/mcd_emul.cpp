@@ -12,18 +12,16 @@ template <int MODEL, bool FREE, bool FAST>
 static void run(int64_t n, const double* recs, const double* wpar, int64_t W, int64_t chunk_len, double* out) {
     constexpr int ND = record_doubles(MODEL, FREE);
     for (int64_t w = 0; w < W; ++w) {
-        const double* p = wpar + w * KD;
         WalkerConsts<double> c;
-        c.vsys = p[W_VSYS]; c.s2 = p[W_S2]; c.vx = p[W_VX]; c.vy = p[W_VY];
-        c.sac = p[W_SAC]; c.cac = p[W_CAC]; c.sdc = p[W_SDC]; c.cdc = p[W_CDC];
-        c.vb = p[W_VB]; c.sb2 = p[W_SB2]; c.fb = p[W_FB];
+        c.load(wpar + w * KD);
         double total = 0.0;
         for (int64_t s = 0; s < n; s += chunk_len) {
             const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
             total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c);
         }
-        if (MODEL == MODEL_BGFIXED && FAST) {        // walker-independent sum of lnL_bg: added by the reduce kernel on the GPU
-            constexpr int XB = FREE ? 6 : 4;
+        if (FAST && (bg_kind(MODEL) == BG_FIXED || bg_kind(MODEL) == BG_FIXED_DENSITY)) {
+            // walker-independent sum of lnL_bg: added by the reduce kernel on the GPU
+            constexpr int XB = geometry_doubles(MODEL, FREE);
             double sb = 0.0;
             for (int64_t i = 0; i < n; ++i) sb += recs[i * ND + XB];
             total += sb;
@@ -32,15 +30,38 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
     }
 }
 
+template <int MODEL, bool FREE>
+static void per_star(int64_t n, const double* recs, const double* wrow, int mode, double* out) {
+    constexpr int ND = record_doubles(MODEL, FREE);
+    WalkerConsts<double> c;
+    c.load(wrow);
+    for (int64_t i = 0; i < n; ++i) {
+        double lc, lb, m;
+        star_components<MODEL, FREE, double>(recs + i * ND, c, lc, lb, m);
+        if (mode == 1) { out[i] = mixture_lnl(lc, lb, m); continue; }
+        const double shift = is_profile(MODEL) ? max_(lc, lb) : 0.0;
+        const double ec = m * std::exp(lc - shift), eb = (1.0 - m) * std::exp(lb - shift);
+        out[i] = ec / (ec + eb);
+    }
+}
+
 extern "C" int emul_record_doubles(int model, int free_centre) { return record_doubles(model, free_centre != 0); }
+extern "C" int emul_geometry_doubles(int model, int free_centre) { return geometry_doubles(model, free_centre != 0); }
 extern "C" int emul_kd() { return KD; }
 
+#define FOR_ALL(M) CASE(M, false, false) CASE(M, false, true) CASE(M, true, false) CASE(M, true, true)
 extern "C" int emul_loglike(int model, int free_centre, int fast, int64_t n, const double* recs, const double* wpar,
                             int64_t W, int64_t chunk_len, double* out) {
 #define CASE(M, F, X) if (model == M && (free_centre != 0) == F && (fast != 0) == X) { run<M, F, X>(n, recs, wpar, W, chunk_len, out); return 0; }
-    CASE(0, false, false) CASE(0, false, true) CASE(0, true, false) CASE(0, true, true)
-    CASE(1, false, false) CASE(1, false, true) CASE(1, true, false) CASE(1, true, true)
-    CASE(2, false, false) CASE(2, false, true) CASE(2, true, false) CASE(2, true, true)
+    FOR_ALL(0) FOR_ALL(1) FOR_ALL(2) FOR_ALL(3) FOR_ALL(4) FOR_ALL(5)
+#undef CASE
+    return -1;
+}
+
+extern "C" int emul_per_star(int model, int free_centre, int mode, int64_t n, const double* recs, const double* wrow,
+                             double* out) {
+#define CASE(M, F, X) if (X && model == M && (free_centre != 0) == F) { per_star<M, F>(n, recs, wrow, mode, out); return 0; }
+    FOR_ALL(1) FOR_ALL(2) FOR_ALL(4) FOR_ALL(5)
 #undef CASE
     return -1;
 }

@@ -133,3 +133,88 @@ def test_mcmc_on_example_catalogue(tmp_path):
     restart = cf.read_final_chain(prefix + "_chain.pkl")
     sampler2 = cf(n_walkers=32, n_steps=5, pos=restart, prefix=None)
     assert np.asarray(sampler2.chain).shape == (32, 5, 4)
+
+
+# ------------------------------------------------------------------------------------------ ModelFit family ("next" row 1)
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit(which):
+    from mcmc_dynamics_amd.analysis import ModelFit
+    g = load_golden("model_fit_" + which)
+    mf = ModelFit(_reader(g))
+    if which == "fixed":
+        _fix(mf, g)
+    assert mf.fitted_parameters == [str(n) for n in g["names"]]       # config/model.json order, centre in the middle
+    assert rel_err(mf.lnprob_batch(g["values"]), g["lnprob"]) < RTOL
+    assert rel_err(np.array([mf.lnprob(row) for row in g["values"][:4]]), g["lnprob"][:4]) < RTOL
+    mf.close()
+    mf._precision = "f32acc64"
+    ok = np.isfinite(g["lnprob"])
+    assert rel_err(mf.lnlike_batch(g["values"][ok]), g["lnprob"][ok]) < 1e-5
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit_gb(which):
+    from mcmc_dynamics_amd.analysis import ModelFitGB
+    g = load_golden("model_fit_gb_" + which)
+    mg = ModelFitGB(_reader(g, ("density",)))
+    if which == "fixed":
+        _fix(mg, g)
+    assert mg.fitted_parameters == [str(n) for n in g["names"]]
+    assert rel_err(mg.lnprob_batch(g["values"]), g["lnprob"]) < RTOL
+    mem = mg.membership_probabilities(g["values"][1])
+    assert mem.shape == (len(g["v"]),) and np.all((mem >= 0) & (mem <= 1))
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit_constant_background(which):
+    from mcmc_dynamics_amd import Gaussian, Parameters
+    from mcmc_dynamics_amd.analysis import ModelFitConstantBackground
+    g = load_golden("model_fit_cb_" + which)
+    pars = ModelFitConstantBackground.default_parameters()
+    del pars["v_back"]
+    del pars["sigma_back"]
+    mc = ModelFitConstantBackground(_reader(g, ("density",)), Gaussian(float(g["bg_mean"]), float(g["bg_sigma"])),
+                                    parameters=pars)
+    if which == "fixed":
+        _fix(mc, g)
+    assert mc.fitted_parameters == [str(n) for n in g["names"]]
+    assert rel_err(mc.lnprob_batch(g["values"]), g["lnprob"]) < RTOL
+    row = g["values"][int(g["no_sum_row"])]
+    per_star = mc.lnlike(row, no_sum=True)                             # model.py:565-623, no_sum=True
+    assert np.max(np.abs(per_star - g["lnlike_no_sum"]) / np.abs(g["lnlike_no_sum"])) < RTOL
+    assert abs(per_star.sum() - mc.lnlike(row)) < 1e-9 * abs(per_star.sum())
+    from oracle import lnprob_numpy as oracle
+    named = dict(zip([str(n) for n in g["names"]], row))
+    if which == "fixed":
+        named["ra_center"], named["dec_center"] = float(g["ra_center"]), float(g["dec_center"])
+    cat = {k: g[k] for k in ("ra", "dec", "v", "verr", "density")}
+    v_los = oracle.model_rotation(cat["ra"], cat["dec"], named["v_sys"], named["v_maxx"], named["v_maxy"], named["r_peak"],
+                                  named["ra_center"], named["dec_center"])
+    sig = oracle.model_dispersion(cat["ra"], cat["dec"], named["sigma_max"], named["a"], named["ra_center"], named["dec_center"])
+    norm = cat["verr"] ** 2 + sig ** 2
+    lc = -0.5 * np.log(2 * np.pi * norm) - 0.5 * (cat["v"] - v_los) ** 2 / norm
+    want = oracle.model_membership(cat, lc, g["lnlike_background"], cat["density"] / (cat["density"] + named["f_back"]))
+    assert np.max(np.abs(mc.membership_probabilities(row) - want)) < 1e-11
+    # host-side model functions agree with the reference's formulas
+    assert np.max(np.abs(mc.rotation_model(named["v_sys"], named["v_maxx"], named["v_maxy"], named["ra_center"],
+                                           named["dec_center"], named["r_peak"]) - v_los)) < 1e-9
+    assert np.max(np.abs(mc.dispersion_model(named["sigma_max"], named["ra_center"], named["dec_center"], named["a"]) - sig)) < 1e-10
+
+
+def test_model_fit_profiles_and_full_size():
+    """create_profiles post-processing, and a 1e6-star ModelFit batch: fast == plain formulation."""
+    from mcmc_dynamics_amd import DataReader, synthetic
+    from mcmc_dynamics_amd.analysis import ModelFit
+    c = synthetic.make_catalog(1000000, config=3)
+    mf = ModelFit(DataReader({k: c[k] for k in ("ra", "dec", "v", "verr")}))
+    mf.parameters["ra_center"].set(value=c["truth"]["ra_center"], fixed=True)
+    mf.parameters["dec_center"].set(value=c["truth"]["dec_center"], fixed=True)
+    rng = np.random.default_rng(5)
+    truth = [0.0, 10.0, 30.0, c["truth"]["v_maxx"], c["truth"]["v_maxy"], 60.0]
+    pos = np.array(truth) * (1.0 + 0.05 * rng.normal(size=(128, 6))) + np.array([0.5, 0, 0, 0, 0, 0]) * rng.normal(size=(128, 1))
+    fast = mf.lnprob_batch(pos)
+    mf._ensure_catalog().set_option("fast_path", 0)
+    assert rel_err(mf.lnprob_batch(pos), fast) < RTOL
+    chain = np.broadcast_to(pos[:, None, :], (128, 12, 6)) * (1.0 + 0.01 * rng.normal(size=(128, 12, 6)))
+    prof = mf.create_profiles(chain, n_burn=2, radii=[10.0, 60.0, 200.0])
+    assert len(prof) == 3 and prof["v_rot"][1] == pytest.approx(5.0, rel=0.2) and prof["sigma"][0] < 10.6

@@ -13,6 +13,9 @@ CASES = [
     ("constant_fixed", 0, False), ("constant_free", 0, True),
     ("constant_bg_gaussian_fixed", 1, False), ("constant_bg_gaussian_free", 1, True),
     ("constant_gb_fixed", 2, False), ("constant_gb_free", 2, True),
+    ("model_fit_fixed", 3, False), ("model_fit_free", 3, True),                 # ModelFit (analysis/model.py)
+    ("model_fit_gb_fixed", 4, False), ("model_fit_gb_free", 4, True),           # ModelFitGB
+    ("model_fit_cb_fixed", 5, False), ("model_fit_cb_free", 5, True),           # ModelFitConstantBackground
 ]
 
 
@@ -24,12 +27,33 @@ def test_host_compiled_kernel_math_matches_reference(name, model, free, fast, ch
     cat = {k: g[k] for k in ("ra", "dec", "v", "verr")}
     if model == 1:
         cat["lnlike_bg"], cat["pmember"] = g["lnlike_background"], g["pmember"]
-    if model == 2:
+    if model in (2, 4, 5):
         cat["density"] = g["density"]
+    if model == 5:
+        cat["lnlike_bg"] = g["lnlike_background"]
     centre = None if free else (float(g["ra_center"]), float(g["dec_center"]))
-    ok = np.isfinite(g["lnprior"])
-    got = emul.loglike(cat, g["values"][ok], model, centre, fast, chunk_len)
+    ok = np.isfinite(g["lnprob"])
+    values = emul.abi_columns(g["names"], g["values"], model, free)
+    got = emul.loglike(cat, values[ok], model, centre, fast, chunk_len)
     assert rel_err(got, g["lnprob"][ok]) < RTOL
+
+
+def test_per_star_outputs():
+    """membership probabilities (constant.py:366-374) and lnlike(no_sum=True) (model.py:565-623)."""
+    g = load_golden("constant_gb_fixed")
+    cat = {k: g[k] for k in ("ra", "dec", "v", "verr", "density")}
+    centre = (float(g["ra_center"]), float(g["dec_center"]))
+    row = emul.abi_columns(g["names"], g["values"], 2, False)[int(g["membership_row"])]
+    assert np.max(np.abs(emul.per_star(cat, row, 2, centre, 0) - g["membership"])) < 1e-12
+    for which, centre_of in (("fixed", lambda g: (float(g["ra_center"]), float(g["dec_center"]))), ("free", lambda g: None)):
+        g = load_golden("model_fit_cb_" + which)
+        cat = {k: g[k] for k in ("ra", "dec", "v", "verr", "density")}
+        cat["lnlike_bg"] = g["lnlike_background"]
+        row = emul.abi_columns(g["names"], g["values"], 5, which == "free")[int(g["no_sum_row"])]
+        got = emul.per_star(cat, row, 5, centre_of(g), 1)
+        assert np.max(np.abs(got - g["lnlike_no_sum"]) / np.abs(g["lnlike_no_sum"])) < 1e-12
+        mem = emul.per_star(cat, row, 5, centre_of(g), 0)
+        assert np.all((mem >= 0) & (mem <= 1))
 
 
 def test_fast_paths_survive_outliers_and_extreme_backgrounds():

@@ -132,3 +132,44 @@ def test_closed_form_known_answer():
     mix = oracle.faithful_constant_lnlike(cat, v_sys, sigma, 1.0, -0.5, 10.0, 0.0, lnbg, np.ones(3))
     plain = oracle.faithful_constant_lnlike(cat, v_sys, sigma, 1.0, -0.5, 10.0, 0.0)
     assert abs(mix - plain) < 1e-13
+
+
+# ------------------------------------------------------------------------------------------ ModelFit family
+def _named(g, row, which):
+    d = dict(zip([str(n) for n in g["names"]], row))
+    if which == "fixed":
+        d["ra_center"], d["dec_center"] = float(g["ra_center"]), float(g["dec_center"])
+    return d
+
+
+CORE = ("v_sys", "sigma_max", "a", "v_maxx", "v_maxy", "r_peak", "ra_center", "dec_center")
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit_family(which):
+    """ModelFit / ModelFitGB / ModelFitConstantBackground (analysis/model.py:93-222, 391-456, 565-623), including
+    the arcmin-vs-arcsec unit reduction astropy performs inside the reference."""
+    g = load_golden("model_fit_" + which)
+    ok = np.isfinite(g["lnprob"])
+    got = np.array([oracle.faithful_model_lnlike(_cat(g), **{k: _named(g, r, which)[k] for k in CORE}) for r in g["values"][ok]])
+    assert rel_err(got, g["lnprob"][ok]) < RTOL and (~ok).sum() == 1
+
+    g = load_golden("model_fit_gb_" + which)
+    ok = np.isfinite(g["lnprob"])
+    keys = CORE + ("v_back", "sigma_back", "f_back")
+    got = np.array([oracle.faithful_model_gb_lnlike(_cat(g, ("density",)), **{k: _named(g, r, which)[k] for k in keys})
+                    for r in g["values"][ok]])
+    assert rel_err(got, g["lnprob"][ok]) < RTOL and (~ok).sum() == 2
+
+    g = load_golden("model_fit_cb_" + which)
+    ok = np.isfinite(g["lnprob"])
+    lnbg = oracle.gaussian_background(g["v"], g["verr"], float(g["bg_mean"]), float(g["bg_sigma"]))
+    assert np.max(np.abs(lnbg - g["lnlike_background"])) < 1e-12
+    keys = CORE + ("f_back",)
+    got = np.array([oracle.faithful_model_cb_lnlike(_cat(g, ("density",)), lnlike_background=lnbg,
+                                                    **{k: _named(g, r, which)[k] for k in keys}) for r in g["values"][ok]])
+    assert rel_err(got, g["lnprob"][ok]) < RTOL
+    row = g["values"][int(g["no_sum_row"])]
+    per_star = oracle.faithful_model_cb_lnlike(_cat(g, ("density",)), lnlike_background=lnbg, no_sum=True,
+                                               **{k: _named(g, row, which)[k] for k in keys})
+    assert np.max(np.abs(per_star - g["lnlike_no_sum"]) / np.abs(g["lnlike_no_sum"])) < RTOL
