@@ -40,6 +40,8 @@ WORKLOADS = {
                 32, 3),
     "c4": ("C4: 1e7 synthetic stars sharded over the GPUs (strong scaling), rotation+dispersion", 10000000, 256,
            "const", 32, 4),
+    "c5": ("C5: radial-binned dispersion profile (make_radial_bins nstars=1000, dlogr=0.05), 1e6 synthetic stars x 512 "
+           "walkers per bin, rotation+dispersion, one segmented launch for all bins", 1000000, 512, "const", 32, 5),
 }
 
 
@@ -51,15 +53,17 @@ def parse_args():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--stars", type=int, default=None, help="stars per GPU (override)")
     ap.add_argument("--walkers", type=int, default=None)
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32", "f32acc64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
     return ap.parse_args()
 
 
-def build_catalog(native, ctx, synthetic, oracle, cat, model):
+def build_catalog(native, ctx, synthetic, oracle, cat, model, precision="f64", bin_offsets=None):
     centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
     if model == "const":
-        return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST, centre=centre)
+        return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST, centre=centre,
+                              precision=precision, bin_offsets=bin_offsets)
     if model == "bgfixed":
         # background/gaussian.py:23-28 evaluated once on the host (one-off precompute)
         from mcmc_dynamics_amd.background import Gaussian
@@ -147,7 +151,20 @@ def main():
     names = ["v_sys", "sigma_max", "v_maxx", "v_maxy"] + (["v_back", "sigma_back", "f_back"] if model == "bggauss" else [])
     pos = synthetic.make_walkers(n_walkers, names, truth, config=config)
 
-    gpu_cat = build_catalog(native, ctx, synthetic, None, cat, model)
+    bin_offsets, n_bins = None, 1
+    if args.workload == "c5":
+        # DataReader.make_radial_bins (utils/files/data_reader.py:71-120), stars sorted by bin; every bin gets its
+        # own copy of the walker ensemble (B independent posteriors per launch)
+        from mcmc_dynamics_amd import DataReader
+        reader = DataReader({k: cat[k] for k in ("ra", "dec", "v", "verr")})
+        reader.make_radial_bins(synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG, nstars=1000, dlogr=0.05)
+        srt, bin_offsets = reader.sorted_by_bin()
+        cat = dict(cat, **{k: srt.data[k] for k in ("ra", "dec", "v", "verr")})
+        n_bins = len(bin_offsets) - 1
+        pos = np.ascontiguousarray(np.broadcast_to(pos, (n_bins,) + pos.shape))
+        bytes_per_term = bytes_per_term if args.precision == "f64" else bytes_per_term // 2
+
+    gpu_cat = build_catalog(native, ctx, synthetic, None, cat, model, args.precision, bin_offsets)
     gpu_cat.set_option("timing", 2)
     gpu_cat.upload_params(pos)
 
@@ -182,6 +199,22 @@ def main():
         gpu_cat.loglike(pos)
     sync_call = (time.perf_counter() - t1) / n_sync
     gpu_cat.timing_collect()
+
+    # sampler-driven end-to-end rate (1 GPU only): the built-in stretch move makes two blocking calls of W/2
+    # proposals per step, exactly the batching emcee's default move produces (hard parts)
+    mcmc = None
+    if world == 1 and n_bins == 1:
+        from mcmc_dynamics_amd.sampler import EnsembleSampler
+        sampler = EnsembleSampler(n_walkers, pos.shape[1], gpu_cat.loglike, vectorize=True, seed=3)
+        sampler.run_mcmc(pos, 3)
+        t2 = time.perf_counter()
+        n_mcmc = 30
+        sampler.run_mcmc(pos, n_mcmc)
+        dt = time.perf_counter() - t2
+        mcmc = {"steps_per_s": n_mcmc / dt, "terms_per_s": float(len(cat["v"])) * n_walkers * n_mcmc / dt,
+                "calls_per_step": 2, "walkers_per_call": n_walkers // 2,
+                "acceptance_fraction": float(np.mean(sampler.acceptance_fraction))}
+        gpu_cat.timing_collect()
 
     if rank != 0:
         if dist is not None:
@@ -223,11 +256,17 @@ def main():
         "sync_call_terms_per_s": local_terms * world / sync_call,
         "sync_call_us": sync_call * 1e6,
         "launch": info,
+        "mcmc_end_to_end": mcmc,
     }
+    out["dtype"] = {"f64": "f64", "f32": "f32", "f32acc64": "f32 terms, f64 accumulation"}[args.precision]
+    if n_bins > 1:
+        out["config"]["radial_bins"] = n_bins
+        out["config"]["outputs_per_step"] = n_bins * n_walkers
     if world == 1 and not args.no_cpu_baseline:
-        base, vals = cpu_baseline(cat, pos, model, args.cpu_seconds)
+        base, vals = cpu_baseline(cat, pos[0] if n_bins > 1 else pos, model, args.cpu_seconds)
         out["cpu_baseline"] = base
-        err = np.max(np.abs(result[:len(vals)] - vals) / np.abs(vals))
+        got = result.sum(axis=0) if n_bins > 1 else result          # same walkers in every bin: sum over bins == un-binned
+        err = np.max(np.abs(got[:len(vals)] - vals) / np.abs(vals))
         out["gpu_vs_cpu_port_max_rel_err"] = float(err)
         out["speedup_vs_cpu_1core"] = value / base["value"]
     else:

@@ -129,6 +129,19 @@ MCD_HD void free_centre_geometry(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T 
     }
 }
 
+// a * b + c with the addend c known to be wave-uniform (a star-record value held in an SGPR pair).  hipcc would
+// otherwise copy c into VGPRs to use the two-address v_fmac_f64 (2 extra v_mov_b32 per use); the three-address
+// VOP3 form takes the SGPR pair directly.
+MCD_HD double fma_sgpr_addend(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#else
+    return std::fma(a, b, c);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // sum of logs as the log of a running product with explicit exponent tracking:
 //   sum_i log(x_i) = log(prod_i m_i) + ln2 * sum_i e_i .
@@ -323,15 +336,16 @@ struct BgFixedAcc {
     LogProduct lden;       // BG_FIXED_DENSITY: sum log(rho_i + f)
     MCD_HD void init() { l.init(); lden.init(); }
     MCD_HD void add_density(double d, double n, double rho, double f, double nbp) {
-        add(d, n, rho, f, nbp);
+        add<false>(d, n, rho, f, nbp);           // f_back is a per-walker (VGPR) value here
         lden.mul(rho + f);
     }
+    template <bool UNIFORM_OMP = true>
     MCD_HD void add(double d, double n, double p, double omp, double nbp) {
         const double g = rsqrt_nr(n);
         const double dg = d * g;
         // |u| <= 1e9 by the host guard (|v - v_los| / sqrt(norm) <= 4e4, |lnL_bg| <= 1e5): k fits an int and e^u
         // is an exact 0 long before the range reduction loses accuracy.
-        const double u = fma_(-0.5 * dg, dg, nbp);
+        const double u = fma_sgpr_addend(-0.5 * dg, dg, nbp);
         int k;
         const double er = exp_split(u, k);
         // y = (1 - p) + p g e^r 2^k.  k > 1000 (cluster likelihood e^693 times the background's) is carried in the
@@ -339,7 +353,7 @@ struct BgFixedAcc {
         // k < -1074 underflows inside ldexp; with p == 1 exactly that gives y = 0 and lnL = -inf, which is also what
         // the reference returns there (runner.py:283: log(1 * exp(m - b) + 0) with exp underflowing).
         const int kc = k > 1000 ? 1000 : k;
-        const double y = fma_(p * g, ldexp_(er, kc), omp);
+        const double y = UNIFORM_OMP ? fma_sgpr_addend(p * g, ldexp_(er, kc), omp) : fma_(p * g, ldexp_(er, kc), omp);
         l.mul_any(y);
         l.e32 += k - kc;
     }
