@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32", "f32acc64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores pool baseline")
     return ap.parse_args()
 
 
@@ -106,6 +107,57 @@ def cpu_baseline(cat, pos, model, budget_s):
                       "{3:.1f} s".format(n, n_stars, np.__version__, dt)}, np.array(vals)
 
 
+_POOL_STATE = {}
+
+
+def _pool_worker(rows):
+    """One walker per call in a forked worker (mirrors the reference's `n_threads` pool over walkers,
+    runner.py:398-403).  Workers inherit the catalogue from the parent and never touch the GPU."""
+    one = _POOL_STATE["one"]
+    t0 = time.perf_counter()
+    for row in rows:
+        one(row)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(cat, pos, model, per_walker_s, budget_s):
+    """The same NumPy port on every host core this process may use.  Must run BEFORE the HIP runtime is
+    initialised (plain fork, no exec); bounded by a hard timeout so that it can never stall the bench."""
+    import multiprocessing as mp
+    from oracle import lnprob_numpy as oracle
+    from mcmc_dynamics_amd import synthetic
+    centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
+    lnbg = None
+    if model == "bgfixed":
+        lnbg = oracle.gaussian_background(cat["v"], cat["verr"], synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])
+
+    def one(row):
+        if model == "bggauss":
+            return oracle.faithful_constant_gb_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
+                                                      row[4], row[5], row[6])
+        return oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
+                                               lnlike_background=lnbg, pmember=cat.get("pmember") if lnbg is not None else None)
+
+    _POOL_STATE["one"] = one
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    per_worker = max(1, min(len(pos) // cores, int(budget_s / max(per_walker_s, 1e-3))))
+    jobs = [pos[i * per_worker:(i + 1) * per_worker] for i in range(cores)]
+    pool = mp.get_context("fork").Pool(cores)
+    try:
+        pool.map_async(_pool_worker, [pos[:1]] * cores).get(timeout=60)           # warm-up outside the timed region
+        t0 = time.perf_counter()
+        busy = pool.map_async(_pool_worker, jobs).get(timeout=max(60.0, 6.0 * budget_s))
+        wall = time.perf_counter() - t0
+    finally:
+        pool.terminate()
+        pool.join()
+    n = per_worker * cores
+    return {"value": len(cat["v"]) * n / wall, "unit": "terms/s", "cores": cores, "kind": "port",
+            "sample": "{0} walkers x {1} stars over {2} forked worker processes (one walker per call each), wall {3:.1f} s "
+                      "(slowest worker busy {4:.1f} s)".format(n, len(cat["v"]), cores, wall, max(busy))}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +166,7 @@ def main():
     if world != max(1, args.gpus) and world > 1:
         raise SystemExit("WORLD_SIZE={0} does not match --gpus {1}".format(world, args.gpus))
 
-    from mcmc_dynamics_amd import _native as native, synthetic
+    from mcmc_dynamics_amd import synthetic
     desc, n_stars, n_walkers, model, bytes_per_term, config = WORKLOADS[args.workload]
     strong = args.workload == "c4"
     if args.stars is not None:
@@ -122,6 +174,22 @@ def main():
     if args.walkers is not None:
         n_walkers = args.walkers
 
+    # Extra CPU figure (all host cores) -- forked workers, so it runs before anything initialises the HIP runtime.
+    all_cores = None
+    if (world == 1 and not args.no_cpu_baseline and not args.no_cpu_all_cores
+            and args.workload in ("c2", "c3", "c3gb", "c3const")):
+        try:
+            cat0 = synthetic.make_catalog(n_stars, config=config, seed=synthetic.CATALOG_SEED_BASE + config,
+                                          background=(model != "const"))
+            names0 = ["v_sys", "sigma_max", "v_maxx", "v_maxy"] + (["v_back", "sigma_back", "f_back"] if model == "bggauss" else [])
+            pos0 = synthetic.make_walkers(n_walkers, names0, cat0["truth"], config=config)
+            probe, _ = cpu_baseline(cat0, pos0[:2], model, 1.0)
+            all_cores = cpu_baseline_all_cores(cat0, pos0, model, n_stars / probe["value"], min(args.cpu_seconds, 10.0))
+            del cat0
+        except Exception as exc:                          # never let the extra baseline break the bench line
+            all_cores = {"error": repr(exc)}
+
+    from mcmc_dynamics_amd import _native as native
     dist = None
     if world > 1:
         import torch.distributed as dist           # host-side rendezvous only (gloo); the data path is RCCL in the library
@@ -269,6 +337,8 @@ def main():
         err = np.max(np.abs(got[:len(vals)] - vals) / np.abs(vals))
         out["gpu_vs_cpu_port_max_rel_err"] = float(err)
         out["speedup_vs_cpu_1core"] = value / base["value"]
+        if all_cores is not None:
+            out["cpu_baseline_all_cores"] = all_cores
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)

@@ -255,7 +255,7 @@ MCD_HD T mixture_lnl(T m, T b, T p) {
 
 // ---------------------------------------------------------------------------------------------
 // Fast mixture paths (f64): no log, no divide per term.
-//   exp(-1/2 d^2/n) / sqrt(n)  is formed from g = n^(-1/2)  (v_rsq_f64 + two Newton steps)
+//   exp(-1/2 d^2/n) / sqrt(n)  is formed from g = n^(-1/2)  (v_rsq_f64 + one third-order Newton step)
 //   and one exp whose argument is <= 0 or exponent-clamped; the per-star mixture value y_i > 0 is
 //   folded into a LogProduct:  sum_i log y_i = log prod_i y_i.
 

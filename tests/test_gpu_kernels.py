@@ -283,3 +283,36 @@ def test_rccl_call_path_on_one_rank(native):
         assert np.array_equal(cat.loglike(pos), ref)
     cat.close()
     ctx1.close()
+
+
+def test_c4_size_shards(native, ctx):
+    """1e7 stars x 256 walkers (C4): the eight 1.25e6-star shards a node would hold sum to the un-sharded value
+    (what the RCCL all-reduce computes), and the sum over radial bins equals it too."""
+    from mcmc_dynamics_amd import distributed, synthetic
+    c, centre = _synthetic(10000000, 4)
+    pos = synthetic.make_walkers(256, NAMES4, c["truth"], config=4)
+    full = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
+    want = full.loglike(pos)
+    assert np.all(np.isfinite(want)) and np.all(want < -3e7)
+    total = np.zeros(256)
+    for rank in range(8):
+        lo, hi = distributed.shard_bounds(10000000, rank, 8)
+        assert hi - lo == 1250000
+        total += native.Catalog(ctx, c["ra"][lo:hi], c["dec"][lo:hi], c["v"][lo:hi], c["verr"][lo:hi],
+                                model=native.MODEL_CONST, centre=centre).loglike(pos)
+    assert rel_err(total, want) < RTOL
+    full.close()
+
+
+def test_single_stars_background(native, ctx):
+    """background.SingleStars (KDE over comparison stars) feeding the fixed-background kernel (runner.py:96-106)."""
+    from mcmc_dynamics_amd import SingleStars, synthetic
+    from oracle import lnprob_numpy as oracle
+    c, centre = _synthetic(4000, 3, background=True)
+    comp = np.random.default_rng(2).normal(20.0, 40.0, size=300)
+    lnbg = SingleStars(comp)(c["v"], c["verr"])
+    pos = synthetic.make_walkers(32, NAMES4, c["truth"], config=3)
+    cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST_BGFIXED, centre=centre,
+                         lnlike_bg=lnbg, pmember=c["pmember"])
+    want = oracle.batched_constant_lnlike(c, pos, *centre, lnlike_background=lnbg, pmember=c["pmember"])
+    assert rel_err(cat.loglike(pos), want) < RTOL
