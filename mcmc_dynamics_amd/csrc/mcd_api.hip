@@ -242,8 +242,10 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
 // Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
 // expressions term by term.
 bool fast_guard(const mcd_catalog* cat, const double* params, int64_t n_rows) {
-    if (!cat->allow_fast || cat->precision != MCD_F64) return false;
+    if (!cat->allow_fast) return false;
     if (!cat->stats_finite || n_rows == 0) return false;
+    const bool f32 = cat->precision != MCD_F64;
+    if (f32 && mcd::bg_kind(cat->model) != mcd::BG_NONE) return false;      // f32 mixtures use the plain kernels
     const int k = cat->k;
     const bool prof = mcd::is_profile(cat->model);
     const int bg = mcd::bg_kind(cat->model);
@@ -286,8 +288,12 @@ bool fast_guard(const mcd_catalog* cat, const double* params, int64_t n_rows) {
     // sigma_los of the profile models decays to 0 at large r: only verr^2 bounds the variance from below
     const double n_min = cat->e2_min + (prof ? 0.0 : s2_min), n_max = cat->e2_max + s2_max;
     if (prof && !(len_min >= std::ldexp(1.0, -100) && len_max <= std::ldexp(1.0, 100))) return false;   // a, r_peak > 0
-    if (bg == mcd::BG_NONE)
+    if (bg == mcd::BG_NONE) {
+        if (f32)      // 4-star tree in f32: DEN <= 2^60, NUM <= 2^77
+            return (n_min >= std::ldexp(1.0, -15)) && (n_max <= std::ldexp(1.0, 15)) && (d_max <= std::ldexp(1.0, 15)) &&
+                   (!prof || (len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20)));
         return (n_min >= std::ldexp(1.0, -60)) && (n_max <= std::ldexp(1.0, 60));
+    }
     const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
     if (!((n_min >= lo) && (n_max <= hi))) return false;
     // exponent arguments stay below 1e9 in magnitude: (|v| + |v_los|)^2 / norm_min <= 1.6e9
@@ -535,8 +541,25 @@ int mcd_ctx_destroy(mcd_ctx* ctx) {
 
 int mcd_ctx_n_devices(const mcd_ctx* ctx) { return ctx ? (int)ctx->slots.size() : 0; }
 
+static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::unique_ptr<mcd_catalog>& cat);
+
 int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** out) {
     if (!ctx || !d || !out) return fail(MCD_ERR_INVALID, "mcd_catalog_create: null argument");
+    std::unique_ptr<mcd_catalog> cat;
+    const int rc = catalog_create_impl(ctx, d, cat);
+    if (rc != MCD_OK) {
+        if (cat) {                                   // release whatever device memory was already allocated
+            const std::string msg = g_last_error;
+            mcd_catalog_destroy(cat.release());
+            g_last_error = msg;
+        }
+        return rc;
+    }
+    *out = cat.release();
+    return MCD_OK;
+}
+
+static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::unique_ptr<mcd_catalog>& cat) {
     if (d->n_stars < 0) return fail(MCD_ERR_INVALID, "negative n_stars");
     if (d->model < 0 || d->model > MCD_MODEL_PROFILE_BGDENS) return fail(MCD_ERR_INVALID, "unknown model");
     const int bgk = mcd::bg_kind(d->model);
@@ -550,7 +573,7 @@ int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** ou
     if (bgk == mcd::BG_FIXED_DENSITY && d->n_stars > 0 && (!d->lnlike_bg || !d->density))
         return fail(MCD_ERR_INVALID, "constant-background model needs lnlike_bg and density columns");
 
-    std::unique_ptr<mcd_catalog> cat(new (std::nothrow) mcd_catalog());
+    cat.reset(new (std::nothrow) mcd_catalog());
     if (!cat) return fail(MCD_ERR_INVALID, "out of memory");
     cat->ctx = ctx;
     cat->model = d->model;
@@ -646,21 +669,21 @@ int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** ou
         if (sh.n == 0) continue;
         // raw columns -> device scratch -> packed records (device-side trig), scratch freed afterwards
         const double* host_cols[7] = {d->ra, d->dec, d->v, d->verr, d->lnlike_bg, d->pmember, d->density};
-        double* dev_cols[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        struct Scratch {                                    // freed on every exit path
+            double* p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            ~Scratch() { for (double* q : p) if (q) (void)hipFree(q); }
+        } dev;
         for (int c = 0; c < 7; ++c) {
             if (!host_cols[c]) continue;
-            MCD_HIP(hipMalloc(&dev_cols[c], (size_t)sh.n * sizeof(double)));
-            MCD_HIP(hipMemcpyAsync(dev_cols[c], host_cols[c] + sh.star_begin, (size_t)sh.n * sizeof(double),
+            MCD_HIP(hipMalloc(&dev.p[c], (size_t)sh.n * sizeof(double)));
+            MCD_HIP(hipMemcpyAsync(dev.p[c], host_cols[c] + sh.star_begin, (size_t)sh.n * sizeof(double),
                                    hipMemcpyHostToDevice, slot.stream));
         }
-        mcd::RawColumns raw{dev_cols[0], dev_cols[1], dev_cols[2], dev_cols[3], dev_cols[4], dev_cols[5], dev_cols[6]};
+        mcd::RawColumns raw{dev.p[0], dev.p[1], dev.p[2], dev.p[3], dev.p[4], dev.p[5], dev.p[6]};
         MCD_HIP(mcd::launch_prepare_records(slot.stream, raw, sh.n, cat->model, cat->free_centre, cat->precision,
                                             d->ra_center, d->dec_center, sh.records));
         MCD_HIP(hipStreamSynchronize(slot.stream));
-        for (int c = 0; c < 7; ++c)
-            if (dev_cols[c]) MCD_HIP(hipFree(dev_cols[c]));
     }
-    *out = cat.release();
     return MCD_OK;
 }
 

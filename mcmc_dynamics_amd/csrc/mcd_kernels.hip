@@ -229,8 +229,14 @@ hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* re
                                                                      n_walkers);
             return launch_one<MODEL, FREE, double, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
         case 1:
+            if (sh.fast && bg_kind(MODEL) == BG_NONE)
+                return launch_one<MODEL, FREE, float, float, bg_kind(MODEL) == BG_NONE>(s, records, chunks, n_chunks, wpar,
+                                                                                       partials, n_walkers);
             return launch_one<MODEL, FREE, float, float, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
         case 2:
+            if (sh.fast && bg_kind(MODEL) == BG_NONE)
+                return launch_one<MODEL, FREE, float, double, bg_kind(MODEL) == BG_NONE>(s, records, chunks, n_chunks, wpar,
+                                                                                        partials, n_walkers);
             return launch_one<MODEL, FREE, float, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
     }
     return hipErrorInvalidValue;

@@ -222,6 +222,59 @@ struct ConstAcc {          // accumulators of one walker over one chunk (MODEL_C
     MCD_HD double finish(int64_t count) { return -0.5 * (fma_((double)count, kLn2Pi, l.value()) + q); }
 };
 
+// float32 counterpart (MCD_F32 / MCD_F32_ACC64): groups of 4 stars so that DEN <= 2^60 and NUM <= 2^77 stay inside the
+// f32 range under the host guard 2^-15 <= n <= 2^15, q <= 2^30.  The quotient sum accumulates in A (float or double).
+struct FracF { float num, den; };
+MCD_HD FracF fracf_leaf2(float q0, float n0, float q1, float n1) {
+    FracF f;
+    f.den = n0 * n1;
+    f.num = fma_(q1, n0, q0 * n1);
+    return f;
+}
+MCD_HD FracF fracf_join(FracF a, FracF b) {
+    FracF f;
+    f.den = a.den * b.den;
+    f.num = fma_(b.num, a.den, a.num * b.den);
+    return f;
+}
+template <class A>
+struct ConstAccF {
+    A q;
+    float p;
+    int e;
+    MCD_HD void init() { q = 0; p = 1.0f; e = 0; }
+    MCD_HD void fold(float x) {
+        int ex;
+#if defined(__HIP_DEVICE_COMPILE__)
+        p = __builtin_frexpf(p * x, &ex);
+#else
+        p = std::frexp(p * x, &ex);
+#endif
+        e += ex;
+    }
+    MCD_HD void add4(const float* qq, const float* nn) {
+        const FracF f = fracf_join(fracf_leaf2(qq[0], nn[0], qq[1], nn[1]), fracf_leaf2(qq[2], nn[2], qq[3], nn[3]));
+#if defined(__HIP_DEVICE_COMPILE__)
+        q += (A)(f.num * __builtin_amdgcn_rcpf(f.den));     // v_rcp_f32: 1 ulp
+#else
+        q += (A)(f.num / f.den);
+#endif
+        fold(f.den);
+    }
+    MCD_HD void add1(float q1, float n1) {
+        q += (A)(q1 / n1);
+        fold(n1);
+    }
+    MCD_HD double finish(int64_t count) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double lg = fma_((double)e, kLn2, log((double)p));
+#else
+        const double lg = fma_((double)e, kLn2, std::log((double)p));
+#endif
+        return -0.5 * (fma_((double)count, kLn2Pi, lg) + (double)q);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Plain per-term forms (robust path and mixtures): one log / exp per term as written in the reference.
 template <class T> MCD_HD T log_(T x) {
@@ -460,8 +513,29 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
     constexpr int BG = bg_kind(MODEL);
     double result;
 
-    if constexpr (BG == BG_NONE && FAST) {
-        // fraction-tree + log-product path (f64 only): 8 stars -> one division, one product factor
+    if constexpr (BG == BG_NONE && FAST && sizeof(T) == 4) {
+        // f32 fraction tree over 4 stars + f32 log-product
+        ConstAccF<A> acc;
+        acc.init();
+        const int n4 = count >> 2;
+        for (int g = 0; g < n4; ++g, r += 4 * ND) {
+            float qq[4], nn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float d;
+                star_d_n<MODEL, float, FREE, true>(r + j * ND, w, d, nn[j]);
+                qq[j] = d * d;
+            }
+            acc.add4(qq, nn);
+        }
+        for (int j = n4 * 4; j < count; ++j, r += ND) {
+            float d, n;
+            star_d_n<MODEL, float, FREE, true>(r, w, d, n);
+            acc.add1(d * d, n);
+        }
+        result = acc.finish(count);
+    } else if constexpr (BG == BG_NONE && FAST) {
+        // fraction-tree + log-product path (f64): 8 stars -> one division, one product factor
         ConstAcc acc;
         acc.init();
         const int n8 = count >> 3;
