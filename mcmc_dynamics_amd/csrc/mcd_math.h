@@ -91,6 +91,7 @@ MCD_HD float fma_(float a, float b, float c) {
 // centre's sines/cosines (angle-addition form of calc_xy_offset.py:30-31 followed by
 // arctan2, constant.py:106-107; the r0 factor cancels).  r == 0 follows numpy's arctan2(+0, -0) = pi.
 MCD_HD double rsqrt_nr(double n);
+MCD_HD double rcp_nr(double x);
 
 // Tangent-plane offsets (x, y) of a star about a walker's centre in units of r0 (radians of the orthographic
 // projection), from the sines/cosines of the star's and the centre's coordinates: the angle-addition form of
@@ -210,7 +211,9 @@ struct ConstAcc {          // accumulators of one walker over one chunk (MODEL_C
     MCD_HD void add8(const double* qq, const double* nn) {
         Frac f = frac_join(frac_join(frac_leaf2(qq[0], nn[0], qq[1], nn[1]), frac_leaf2(qq[2], nn[2], qq[3], nn[3])),
                            frac_join(frac_leaf2(qq[4], nn[4], qq[5], nn[5]), frac_leaf2(qq[6], nn[6], qq[7], nn[7])));
-        q += f.num / f.den;
+        // DEN is a normal number far from the range limits (host guard), so the IEEE division's scaling and
+        // fix-up instructions are not needed: reciprocal (v_rcp_f64 + one residual step, < 1 ulp) times NUM.
+        q += f.num * rcp_nr(f.den);
         l.mul(f.den);
         l.rescale();
     }
