@@ -26,6 +26,58 @@ from ..utils.results import ResultsTable
 logger = logging.getLogger(__name__)
 
 
+class _BatchPlan(object):
+    """Everything `lnprob_batch` needs from `self.parameters`, flattened into index arrays once per
+    parameter configuration: the per-call host work is then a handful of NumPy operations on a (W, n_all)
+    array instead of a Python loop over parameters (the reference spends ~0.1 ms per walker here,
+    SURVEY.md section 8(a) A2/A3)."""
+
+    def __init__(self, runner):
+        pars = runner.parameters
+        self.names = list(pars)
+        index = {n: i for i, n in enumerate(self.names)}
+        self.n_all = len(self.names)
+        self.free_idx = np.array([i for i, p in enumerate(pars.values()) if not p.fixed], dtype=np.intp)
+        fixed = [(i, p) for i, p in enumerate(pars.values()) if p.fixed and p._expr is None]
+        self.fixed_idx = np.array([i for i, _ in fixed], dtype=np.intp)
+        self.fixed_val = np.array([float(p._value) for _, p in fixed], dtype=np.float64)
+        self.simple = all(p._expr is None and p._lnprior is None for p in pars.values())
+        self.lo, self.hi = pars.bounds()
+        self.unbounded = bool(np.all(np.isneginf(self.lo)) and np.all(np.isposinf(self.hi)))
+        # kernel table columns (C-ABI order) and unit factors
+        key, _ = runner._catalog_spec()
+        cols = list(runner._KERNEL_HEAD)
+        if key[1] is None:
+            cols += [("ra_center", "deg"), ("dec_center", "deg")]
+        cols += list(runner._KERNEL_TAIL)
+        self.kernel_idx = np.array([index[n] for n, _ in cols], dtype=np.intp)
+        fac = [units.conversion_factor(pars[n].unit, u) if (pars[n].unit and u) else 1.0 for n, u in cols]
+        self.kernel_fac = None if all(f == 1.0 for f in fac) else np.array(fac, dtype=np.float64)
+        self.catalog_key = key
+
+    @staticmethod
+    def signature(runner):
+        return tuple((p.fixed, p._value if p.fixed else None, p.min, p.max, p._expr, p._lnprior, p.unit)
+                     for p in runner.parameters.values())
+
+    def full(self, values):
+        out = np.empty((values.shape[0], self.n_all), dtype=np.float64)
+        out[:, self.free_idx] = values
+        if self.fixed_idx.size:
+            out[:, self.fixed_idx] = self.fixed_val
+        return out
+
+    def prior_ok(self, full):
+        """Boolean (W,): every parameter inside its inclusive bounds (NaN counts as outside)."""
+        if self.unbounded:
+            return ~np.isnan(full).any(axis=1)
+        return ((full >= self.lo) & (full <= self.hi)).all(axis=1)
+
+    def table(self, full):
+        t = full[:, self.kernel_idx]
+        return t if self.kernel_fac is None else t * self.kernel_fac
+
+
 class Runner(object):
     """Parent of the analysis classes.  Sub-classes name the observables and model parameters they
     need (``OBSERVABLES``, ``MODEL_PARAMETERS``) and implement ``_lnlike_batch``."""
@@ -175,10 +227,36 @@ class Runner(object):
         resolved = self.parameters.resolve_batch(values)
         return self._lnlike_batch(resolved)
 
+    def _plan(self):
+        sig = _BatchPlan.signature(self)
+        if getattr(self, "_plan_sig", None) != sig:
+            self._plan_cache = _BatchPlan(self)
+            self._plan_sig = sig
+        return self._plan_cache
+
     def lnprob_batch(self, values):
         """(W, P) -> (W,) log-posteriors.  Walkers outside the prior get -inf; their rows are replaced by
         a valid row for the launch and masked afterwards (the reference skips the evaluation)."""
         values = np.atleast_2d(np.asarray(values, dtype=np.float64))
+        plan = self._plan()
+        if plan.simple and values.shape[1] == plan.free_idx.size:
+            # fast host path: flat bounds, no expression priors / constraints
+            full = plan.full(values)
+            ok = plan.prior_ok(full)
+            out = np.full(values.shape[0], -np.inf)
+            n_ok = int(ok.sum())
+            if n_ok == 0:
+                return out
+            if n_ok != ok.size:
+                full[~ok] = full[int(np.flatnonzero(ok)[0])]
+            cat = self._catalog
+            if cat is None or plan.catalog_key != self._catalog_key:
+                cat = self._ensure_catalog()
+            ll = cat.loglike(plan.table(full))
+            if n_ok == ok.size:
+                return ll
+            out[ok] = ll[ok]
+            return out
         resolved = self.parameters.resolve_batch(values)
         lp = self.parameters.lnprior_batch(resolved)
         ok = np.isfinite(lp)
@@ -384,6 +462,10 @@ class Runner(object):
         return {}
 
     def _ensure_catalog(self):
+        plan = getattr(self, "_plan_cache", None)
+        if (self._catalog is not None and plan is not None and self._plan_sig == _BatchPlan.signature(self)
+                and plan.catalog_key == self._catalog_key):
+            return self._catalog                          # nothing about the parameters changed since the plan was built
         key, spec = self._catalog_spec()
         if self._catalog is None or key != self._catalog_key:
             if self._catalog is not None:

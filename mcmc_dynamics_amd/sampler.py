@@ -69,7 +69,7 @@ class EnsembleSampler(object):
     # ------------------------------------------------------------------ posterior calls
     def compute_log_prob(self, coords):
         coords = np.asarray(coords, dtype=np.float64)
-        if np.any(np.isinf(coords)) or np.any(np.isnan(coords)):
+        if not np.isfinite(coords).all():
             raise ValueError("At least one parameter value was infinite or NaN")
         if self.vectorize:
             lp = np.asarray(self.log_prob_fn(coords), dtype=np.float64)
@@ -80,7 +80,7 @@ class EnsembleSampler(object):
         self.n_calls += 1
         if lp.shape != (coords.shape[0],):
             raise ValueError("log_prob_fn returned shape {0} for {1} positions".format(lp.shape, coords.shape[0]))
-        if np.any(np.isnan(lp)):
+        if np.isnan(lp).any():
             raise ValueError("Probability function returned NaN")
         return lp
 
@@ -96,23 +96,29 @@ class EnsembleSampler(object):
         if np.shape(lnp) != (self.nwalkers,):
             raise ValueError("incompatible input dimensions for log_prob0")
         if store:
-            grow = self.iteration + int(nsteps) - self._chain.shape[0]
-            if grow > 0:
-                self._chain = np.concatenate([self._chain, np.empty((grow, self.nwalkers, self.ndim))])
-                self._lnprob = np.concatenate([self._lnprob, np.empty((grow, self.nwalkers))])
+            need = self.iteration + int(nsteps)
+            if need > self._chain.shape[0]:               # geometric growth: amortised O(1) per stored step
+                cap = max(need, 2 * self._chain.shape[0])
+                chain = np.empty((cap, self.nwalkers, self.ndim))
+                lnprob = np.empty((cap, self.nwalkers))
+                chain[:self.iteration] = self._chain[:self.iteration]
+                lnprob[:self.iteration] = self._lnprob[:self.iteration]
+                self._chain, self._lnprob = chain, lnprob
         half = self.nwalkers // 2
         rnd = self._random
         for _ in range(int(nsteps)):
             order = rnd.permutation(self.nwalkers)
-            for first, second in ((order[:half], order[half:]), (order[half:], order[:half])):
-                s, c = pos[first], pos[second]
-                ns = len(first)
-                zz = ((self.a - 1.0) * rnd.rand(ns) + 1.0) ** 2.0 / self.a
-                partners = c[rnd.randint(len(second), size=ns)]
-                proposal = partners - (partners - s) * zz[:, None]
+            u = rnd.rand(4, half)                          # stretch factors and acceptance draws of both half-steps
+            zz2 = ((self.a - 1.0) * u[:2] + 1.0) ** 2.0 / self.a
+            lz2 = (self.ndim - 1.0) * np.log(zz2)
+            lu2 = np.log(u[2:])
+            pick2 = rnd.randint(half, size=(2, half))
+            for h, (first, second) in enumerate(((order[:half], order[half:]), (order[half:], order[:half]))):
+                s = pos[first]
+                partners = pos[second[pick2[h]]]
+                proposal = partners - (partners - s) * zz2[h][:, None]
                 new_lnp = self.compute_log_prob(proposal)
-                lnpdiff = (self.ndim - 1.0) * np.log(zz) + new_lnp - lnp[first]
-                accept = np.log(rnd.rand(ns)) < lnpdiff
+                accept = lu2[h] < lz2[h] + new_lnp - lnp[first]
                 idx = first[accept]
                 pos[idx] = proposal[accept]
                 lnp[idx] = new_lnp[accept]
