@@ -272,17 +272,29 @@ def main():
     # proposals per step, exactly the batching emcee's default move produces (hard parts)
     mcmc = None
     if world == 1 and n_bins == 1:
-        from mcmc_dynamics_amd.sampler import EnsembleSampler
-        sampler = EnsembleSampler(n_walkers, pos.shape[1], gpu_cat.loglike, vectorize=True, seed=3)
-        sampler.run_mcmc(pos, 3)
+        import logging
+        from mcmc_dynamics_amd import DataReader, Gaussian
+        from mcmc_dynamics_amd.analysis import ConstantFit, ConstantFitGB
+        logging.getLogger("mcmc_dynamics_amd").setLevel(logging.ERROR)
+        cols = {k: cat[k] for k in ("ra", "dec", "v", "verr", "density", "pmember") if k in cat}
+        if model == "bggauss":
+            fit = ConstantFitGB(DataReader(cols), context=ctx)
+        else:
+            fit = ConstantFit(DataReader(cols), context=ctx,
+                              background=Gaussian(synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"]) if model == "bgfixed" else None)
+        fit.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)     # pattern of bin/run_tests.py:92-93
+        fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
+        sampler = fit._make_sampler(n_walkers)             # emcee if importable, built-in stretch move otherwise
+        state = sampler.run_mcmc(pos, 3)
         t2 = time.perf_counter()
         n_mcmc = 30
-        sampler.run_mcmc(pos, n_mcmc)
+        sampler.run_mcmc(tuple(state)[0], n_mcmc)
         dt = time.perf_counter() - t2
         mcmc = {"steps_per_s": n_mcmc / dt, "terms_per_s": float(len(cat["v"])) * n_walkers * n_mcmc / dt,
-                "calls_per_step": 2, "walkers_per_call": n_walkers // 2,
+                "driver": type(sampler).__module__ + "." + type(sampler).__name__,
+                "posterior": type(fit).__name__ + ".lnprob_batch", "calls_per_step": 2, "walkers_per_call": n_walkers // 2,
                 "acceptance_fraction": float(np.mean(sampler.acceptance_fraction))}
-        gpu_cat.timing_collect()
+        fit.close()
 
     if rank != 0:
         if dist is not None:

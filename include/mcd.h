@@ -164,7 +164,10 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *                      event pair per main-kernel launch for mcd_timing_collect
  *   "fast_path"     0: always use the plain per-term log/divide kernels (default 1: the fraction-tree /
  *                      log-product kernel is used whenever the per-call range guard allows it)
- *   "target_waves"  number of waves the chunking aims for per device (default 16384)
+ *   "target_waves"  number of waves the chunking aims for per device (default 12288)
+ *   "tail_split"    chunk schedule: 0 equal-length chunks; 1 (default): the last ~15 % of a large parameter set is
+ *                      cut into half- and quarter-length chunks so that the launch ends on short waves; 2-4:
+ *                      other guided schedules kept for tuning (see build_workset in mcd_api.hip)
  * Returns MCD_ERR_INVALID for an unknown key. */
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value);
 /* With "timing" = 2: waits for the device, returns the summed HIP-event duration (ms) of all main-kernel

@@ -147,7 +147,8 @@ struct mcd_catalog {
     bool timing = false;
     bool timing_all = false;           // keep an event pair for every launch (measurement harness)
     bool allow_fast = true;
-    int64_t target_waves = 16384;
+    int tail_split = 1;                // guided chunk schedule (shorter chunks at the end of a launch)
+    int64_t target_waves = 12288;
     // state of the last evaluation
     int64_t cur_walkers = 0;
     double last_kernel_ms = -1.0, last_device_ms = -1.0;
@@ -193,7 +194,7 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
 
     const int64_t n_wtiles = (n_walkers + 63) / 64;
     int64_t len = (sh.n * n_wtiles + cat->target_waves - 1) / std::max<int64_t>(1, cat->target_waves);
-    len = std::max<int64_t>(64, round_up(len, 8));
+    len = std::max<int64_t>(64, round_up(len, 32));          // quarter-length tail chunks stay multiples of 8
 
     std::vector<mcd::Chunk> chunks;
     std::vector<int64_t> offs(cat->n_psets + 1, 0);
@@ -202,12 +203,27 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
         offs[p] = (int64_t)chunks.size();
         const int64_t b0 = std::max(cat->bin_offsets[p], sh.star_begin);
         const int64_t b1 = std::min(cat->bin_offsets[p + 1], sh.star_begin + sh.n);
-        for (int64_t s = b0; s < b1; s += len) {
+        // Guided schedule: workgroups are dispatched in chunk order, so the end of a large parameter set is cut
+        // into shorter chunks -- the waves that finish the launch are short, which trims the idle tail of the
+        // last occupancy round.  (tail_split: 0 equal chunks; 1 = 85/10/5 % at len, len/2, len/4; 2 = 70/15/10/5 %
+        // down to len/8; 3, 4 = guided self-scheduling, chunk = remaining work / (G x resident waves).)
+        const int64_t total = b1 - b0;
+        const int mode = (total >= 16 * len && len >= 128) ? cat->tail_split : 0;
+        const int64_t resident_chunks = std::max<int64_t>(1, 8192 / n_wtiles);
+        for (int64_t s = b0; s < b1;) {
+            const int64_t done = s - b0, rem = b1 - s;
+            int64_t step = len;
+            if (mode == 1) step = done * 100 < total * 85 ? len : (done * 100 < total * 95 ? len / 2 : len / 4);
+            else if (mode == 2) step = done * 100 < total * 70 ? len : (done * 100 < total * 85 ? len / 2 : (done * 100 < total * 95 ? len / 4 : len / 8));
+            else if (mode == 3) step = std::min(len, std::max<int64_t>(64, rem / (2 * resident_chunks) / 8 * 8));
+            else if (mode == 4) step = std::min(len, std::max<int64_t>(128, rem / resident_chunks / 8 * 8));
+            step = std::max<int64_t>(8, step / 8 * 8);
             mcd::Chunk c;
             c.begin = s - sh.star_begin;
-            c.count = (int32_t)std::min(len, b1 - s);
+            c.count = (int32_t)std::min(step, rem);
             c.pset = (int32_t)p;
             chunks.push_back(c);
+            s += step;
         }
         max_per = std::max<int64_t>(max_per, (int64_t)chunks.size() - offs[p]);
     }
@@ -219,17 +235,26 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     w.max_chunks_per_pset = max_per;
     const int64_t n_out = cat->n_psets * n_walkers;
     const size_t term_bytes = cat->precision == MCD_F64 ? 8 : 4;
-    MCD_HIP(hipMalloc(&w.d_chunks, std::max<size_t>(1, chunks.size()) * sizeof(mcd::Chunk)));
-    MCD_HIP(hipMalloc(&w.d_offsets, offs.size() * sizeof(int64_t)));
-    MCD_HIP(hipMalloc(&w.d_params, (size_t)n_out * cat->k * sizeof(double)));
-    MCD_HIP(hipMalloc(&w.d_wpar, (size_t)n_out * mcd::KD * term_bytes));
-    MCD_HIP(hipMalloc(&w.d_partials, std::max<size_t>(1, (size_t)n_walkers * w.n_chunks) * sizeof(double)));
-    MCD_HIP(hipMalloc(&w.d_out, (size_t)n_out * sizeof(double)));
-    MCD_HIP(hipHostMalloc(&w.h_params, (size_t)n_out * cat->k * sizeof(double), hipHostMallocDefault));
-    MCD_HIP(hipHostMalloc(&w.h_out, (size_t)n_out * sizeof(double), hipHostMallocDefault));
-    if (!chunks.empty())
-        MCD_HIP(hipMemcpy(w.d_chunks, chunks.data(), chunks.size() * sizeof(mcd::Chunk), hipMemcpyHostToDevice));
-    MCD_HIP(hipMemcpy(w.d_offsets, offs.data(), offs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    auto allocate = [&]() -> hipError_t {
+        hipError_t e;
+        if ((e = hipMalloc(&w.d_chunks, std::max<size_t>(1, chunks.size()) * sizeof(mcd::Chunk))) != hipSuccess) return e;
+        if ((e = hipMalloc(&w.d_offsets, offs.size() * sizeof(int64_t))) != hipSuccess) return e;
+        if ((e = hipMalloc(&w.d_params, (size_t)n_out * cat->k * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&w.d_wpar, (size_t)n_out * mcd::KD * term_bytes)) != hipSuccess) return e;
+        if ((e = hipMalloc(&w.d_partials, std::max<size_t>(1, (size_t)n_walkers * w.n_chunks) * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&w.d_out, (size_t)n_out * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipHostMalloc(&w.h_params, (size_t)n_out * cat->k * sizeof(double), hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipHostMalloc(&w.h_out, (size_t)n_out * sizeof(double), hipHostMallocDefault)) != hipSuccess) return e;
+        if (!chunks.empty() &&
+            (e = hipMemcpy(w.d_chunks, chunks.data(), chunks.size() * sizeof(mcd::Chunk), hipMemcpyHostToDevice)) != hipSuccess)
+            return e;
+        return hipMemcpy(w.d_offsets, offs.data(), offs.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    };
+    const hipError_t err = allocate();
+    if (err != hipSuccess) {
+        free_workset(w);
+        return fail(MCD_ERR_HIP, std::string("work buffers for this walker count: ") + hipGetErrorString(err));
+    }
     auto ins = sh.work.emplace(n_walkers, w);
     *out = &ins.first->second;
     return MCD_OK;
@@ -352,6 +377,7 @@ int enqueue(mcd_catalog* cat) {
         mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast};
         hipEvent_t k0 = sh.ev_k0, k1 = sh.ev_k1;
         if (cat->timing_all) {
+            if (sh.ring_used >= (size_t)1 << 16) sh.ring_used = 0;        // harness option left on: recycle, never grow without bound
             if (sh.ring_used == sh.ring.size()) {
                 hipEvent_t a, b;
                 MCD_HIP(hipEventCreate(&a));
@@ -774,11 +800,13 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     if (!std::strcmp(key, "fast_path")) { cat->allow_fast = value != 0; return MCD_OK; }
-    if (!std::strcmp(key, "target_waves")) {
-        if (value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");
+    if (!std::strcmp(key, "tail_split") || !std::strcmp(key, "target_waves")) {
+        const bool is_split = key[1] == 'a' && key[0] == 't' && key[2] == 'i';
+        if (!is_split && value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");
         int rc = sync_all(cat);
         if (rc != MCD_OK) return rc;
-        cat->target_waves = value;
+        if (is_split) cat->tail_split = (int)value;
+        else cat->target_waves = value;
         for (Shard& sh : cat->shards) {            // chunk tables depend on it: rebuild lazily
             (void)hipSetDevice(cat->ctx->slots[sh.slot].device);
             for (auto& kv : sh.work) free_workset(kv.second);

@@ -33,3 +33,21 @@ def rel_err(got, want):
     if not fin.any():
         return 0.0
     return float(np.max(np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-300)))
+
+
+def ensure_library_built():
+    """Build libmcd_hip.so in-tree when it is missing or older than its sources (hipcc cross-compiles
+    for gfx950 without a GPU).  Returns the path."""
+    import subprocess
+    csrc = os.path.join(ROOT, "mcmc_dynamics_amd", "csrc")
+    lib = os.path.join(ROOT, "mcmc_dynamics_amd", "libmcd_hip.so")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))] + \
+           [os.path.join(ROOT, "include", "mcd.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in srcs):
+        subprocess.run(["make", "-C", csrc, "-j4"], check=True, capture_output=True)
+    return lib
+
+
+@pytest.fixture(scope="session")
+def built_library():
+    return ensure_library_built()

@@ -35,7 +35,7 @@ def small_reader(n=300, background=True):
 
 
 # ------------------------------------------------------------------------------------------ native library
-def test_library_exports_every_declared_symbol():
+def test_library_exports_every_declared_symbol(built_library):
     header = open(os.path.join(ROOT, "include", "mcd.h")).read()
     declared = set(re.findall(r"\b(mcd_[a-z_0-9]+)\s*\(", header))
     declared -= {"mcd_ctx", "mcd_catalog"}
@@ -47,7 +47,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.mcd_abi_version() == 1
 
 
-def test_no_cpu_fallback():
+def test_no_cpu_fallback(built_library):
     """Without a usable gfx950 device the product path must fail loudly, not compute on the host."""
     lib = _native.load_library()
     import ctypes
