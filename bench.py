@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores pool baseline")
+    ap.add_argument("--no-mcmc", action="store_true", help="skip the sampler-driven end-to-end figure (profiling runs)")
     return ap.parse_args()
 
 
@@ -261,17 +262,17 @@ def main():
     info = gpu_cat.launch_info()
 
     # blocking C-ABI call (host params in, host results out) for the PCIe/sync-inclusive rate
+    gpu_cat.set_option("timing", 0)
     t1 = time.perf_counter()
     n_sync = max(5, min(50, args.steps))
     for _ in range(n_sync):
         gpu_cat.loglike(pos)
     sync_call = (time.perf_counter() - t1) / n_sync
-    gpu_cat.timing_collect()
 
     # sampler-driven end-to-end rate (1 GPU only): the built-in stretch move makes two blocking calls of W/2
     # proposals per step, exactly the batching emcee's default move produces (hard parts)
     mcmc = None
-    if world == 1 and n_bins == 1:
+    if world == 1 and n_bins == 1 and not args.no_mcmc:
         import logging
         from mcmc_dynamics_amd import DataReader, Gaussian
         from mcmc_dynamics_amd.analysis import ConstantFit, ConstantFitGB
