@@ -164,6 +164,8 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *                      event pair per main-kernel launch for mcd_timing_collect
  *   "fast_path"     0: always use the plain per-term log/divide kernels (default 1: the fraction-tree /
  *                      log-product kernel is used whenever the per-call range guard allows it)
+ *   "zero_copy"     1 (default): on a single device mcd_loglike_batch lets the kernels read the parameter table
+ *                      from / write the results to pinned mapped host memory instead of issuing H2D / D2H copies
  *   "target_waves"  number of waves the chunking aims for per device (default 12288)
  *   "tail_split"    chunk schedule: 0 equal-length chunks; 1 (default): the last ~15 % of a large parameter set is
  *                      cut into half- and quarter-length chunks so that the launch ends on short waves; 2-4:

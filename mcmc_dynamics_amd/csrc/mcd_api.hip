@@ -93,14 +93,18 @@ struct WorkSet {
     int64_t n_walkers = 0;
     int64_t n_chunks = 0;
     int64_t max_chunks_per_pset = 0;
+    int uniform_len = 0;               // > 0 when the chunk table is arithmetic (single set, equal lengths)
     mcd::Chunk* d_chunks = nullptr;
     int64_t* d_offsets = nullptr;      // [n_psets + 1] chunk offsets
     double* d_params = nullptr;        // [n_psets][W][K]
     void* d_wpar = nullptr;            // [n_psets][W][KD]
     double* d_partials = nullptr;      // [W][n_chunks]
     double* d_out = nullptr;           // [n_psets][W]
-    double* h_params = nullptr;        // pinned
-    double* h_out = nullptr;           // pinned
+    double* h_params = nullptr;        // pinned + mapped
+    double* h_out = nullptr;           // pinned + mapped
+    double* m_params = nullptr;        // device view of h_params (zero-copy path of the blocking call)
+    double* m_out = nullptr;           // device view of h_out
+    bool mapped = false;               // last staging used the zero-copy path: results land in h_out directly
     bool fast = false;
     bool staged = false;
 };
@@ -147,6 +151,7 @@ struct mcd_catalog {
     bool timing = false;
     bool timing_all = false;           // keep an event pair for every launch (measurement harness)
     bool allow_fast = true;
+    bool zero_copy = true;             // blocking call reads params / writes results through mapped pinned memory
     int tail_split = 1;                // guided chunk schedule (shorter chunks at the end of a launch)
     int64_t target_waves = 12288;
     // state of the last evaluation
@@ -233,6 +238,12 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     w.n_walkers = n_walkers;
     w.n_chunks = (int64_t)chunks.size();
     w.max_chunks_per_pset = max_per;
+    if (cat->n_psets == 1 && !chunks.empty() && len < (int64_t)1 << 30) {
+        bool uniform = true;
+        for (size_t i = 0; i < chunks.size() && uniform; ++i)
+            uniform = chunks[i].begin == (int64_t)i * len && chunks[i].count == (int32_t)std::min<int64_t>(len, sh.n - (int64_t)i * len);
+        if (uniform) w.uniform_len = (int)len;
+    }
     const int64_t n_out = cat->n_psets * n_walkers;
     const size_t term_bytes = cat->precision == MCD_F64 ? 8 : 4;
     auto allocate = [&]() -> hipError_t {
@@ -243,8 +254,10 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
         if ((e = hipMalloc(&w.d_wpar, (size_t)n_out * mcd::KD * term_bytes)) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_partials, std::max<size_t>(1, (size_t)n_walkers * w.n_chunks) * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_out, (size_t)n_out * sizeof(double))) != hipSuccess) return e;
-        if ((e = hipHostMalloc(&w.h_params, (size_t)n_out * cat->k * sizeof(double), hipHostMallocDefault)) != hipSuccess) return e;
-        if ((e = hipHostMalloc(&w.h_out, (size_t)n_out * sizeof(double), hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipHostMalloc(&w.h_params, (size_t)n_out * cat->k * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
+        if ((e = hipHostMalloc(&w.h_out, (size_t)n_out * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
+        if ((e = hipHostGetDevicePointer((void**)&w.m_params, w.h_params, 0)) != hipSuccess) return e;
+        if ((e = hipHostGetDevicePointer((void**)&w.m_out, w.h_out, 0)) != hipSuccess) return e;
         if (!chunks.empty() &&
             (e = hipMemcpy(w.d_chunks, chunks.data(), chunks.size() * sizeof(mcd::Chunk), hipMemcpyHostToDevice)) != hipSuccess)
             return e;
@@ -333,7 +346,7 @@ bool fast_guard(const mcd_catalog* cat, const double* params, int64_t n_rows) {
     return true;
 }
 
-int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params) {
+int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, bool zero_copy) {
     if (!cat || !params) return fail(MCD_ERR_INVALID, "null catalogue or params");
     if (n_walkers <= 0) return fail(MCD_ERR_INVALID, "n_walkers must be positive");
     if (k != cat->k) {
@@ -352,9 +365,17 @@ int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* p
         // the pinned staging buffer may still be in flight from the previous call
         MCD_HIP(hipStreamSynchronize(slot.stream));
         std::memcpy(w->h_params, params, (size_t)n_rows * k * sizeof(double));
-        MCD_HIP(hipMemcpyAsync(w->d_params, w->h_params, (size_t)n_rows * k * sizeof(double), hipMemcpyHostToDevice,
-                               slot.stream));
-        MCD_HIP(mcd::launch_prepare_walkers(slot.stream, w->d_params, n_rows, k, cat->model, cat->free_centre,
+        // Blocking single-device call: the walker-prep kernel reads the pinned host table over PCIe and the reduce
+        // kernel writes the results straight into pinned host memory -- no copy-engine operations on the critical
+        // path.  The pipelined API and multi-device contexts keep device-resident tables.
+        w->mapped = zero_copy;
+        const double* src = w->m_params;
+        if (!zero_copy) {
+            MCD_HIP(hipMemcpyAsync(w->d_params, w->h_params, (size_t)n_rows * k * sizeof(double), hipMemcpyHostToDevice,
+                                   slot.stream));
+            src = w->d_params;
+        }
+        MCD_HIP(mcd::launch_prepare_walkers(slot.stream, src, n_rows, k, cat->model, cat->free_centre,
                                             cat->precision, w->d_wpar));
         w->fast = fast;
         w->staged = true;
@@ -374,7 +395,7 @@ int enqueue(mcd_catalog* cat) {
         if (!w.staged) return fail(MCD_ERR_INVALID, "no parameters staged for this walker count");
         const DeviceSlot& slot = ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
-        mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast};
+        mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast, w.uniform_len, sh.n};
         hipEvent_t k0 = sh.ev_k0, k1 = sh.ev_k1;
         if (cat->timing_all) {
             if (sh.ring_used >= (size_t)1 << 16) sh.ring_used = 0;        // harness option left on: recycle, never grow without bound
@@ -397,7 +418,7 @@ int enqueue(mcd_catalog* cat) {
         const double* pset_const =
             (w.fast && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
         MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, w.n_chunks,
-                                   w.max_chunks_per_pset, W, pset_const, w.d_out));
+                                   w.max_chunks_per_pset, W, pset_const, w.mapped ? w.m_out : w.d_out));
     }
     // sum the per-device / per-rank partial log-likelihoods: one all-reduce of n_out doubles
     const bool collective = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
@@ -461,7 +482,8 @@ int fetch(mcd_catalog* cat, double* out) {
     WorkSet& w = sh.work.at(W);
     const DeviceSlot& slot = cat->ctx->slots[sh.slot];
     MCD_HIP(hipSetDevice(slot.device));
-    MCD_HIP(hipMemcpyAsync(w.h_out, w.d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
+    if (!w.mapped)
+        MCD_HIP(hipMemcpyAsync(w.h_out, w.d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
     int rc = sync_all(cat);
     if (rc != MCD_OK) return rc;
     std::memcpy(out, w.h_out, (size_t)n_out * sizeof(double));
@@ -738,7 +760,7 @@ int64_t mcd_catalog_n_outputs(const mcd_catalog* cat, int64_t n_walkers) {
 }
 
 int mcd_params_upload(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params) {
-    return stage_params(cat, n_walkers, k, params);
+    return stage_params(cat, n_walkers, k, params, false);
 }
 
 int mcd_loglike_enqueue(mcd_catalog* cat) { return enqueue(cat); }
@@ -747,7 +769,8 @@ int mcd_sync(mcd_catalog* cat) { return sync_all(cat); }
 
 int mcd_loglike_batch(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, double* out) {
     if (!out) return fail(MCD_ERR_INVALID, "null output");
-    int rc = stage_params(cat, n_walkers, k, params);
+    const bool collective = cat && (cat->ctx->n_ranks > 1 || cat->ctx->slots.size() > 1 || cat->ctx->force_collective);
+    int rc = stage_params(cat, n_walkers, k, params, !collective && cat && cat->zero_copy);
     if (rc != MCD_OK) return rc;
     rc = enqueue(cat);
     if (rc != MCD_OK) return rc;
@@ -800,6 +823,7 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     if (!std::strcmp(key, "fast_path")) { cat->allow_fast = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "zero_copy")) { cat->zero_copy = value != 0; return MCD_OK; }
     if (!std::strcmp(key, "tail_split") || !std::strcmp(key, "target_waves")) {
         const bool is_split = key[1] == 'a' && key[0] == 't' && key[2] == 'i';
         if (!is_split && value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");

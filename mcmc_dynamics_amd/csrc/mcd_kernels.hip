@@ -119,7 +119,8 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
                                                           const Chunk* __restrict__ chunks,
                                                           const T* __restrict__ wpar,
                                                           double* __restrict__ partials, int64_t n_tasks,
-                                                          int n_wtiles, int64_t n_walkers, int64_t n_chunks) {
+                                                          int n_wtiles, int64_t n_walkers, int64_t n_chunks,
+                                                          int uniform_len, int64_t n_records) {
     constexpr int ND = record_doubles(MODEL, FREE);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kWave - 1);
@@ -127,7 +128,17 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
     if (task >= n_tasks) return;
     const int64_t chunk_id = task / n_wtiles;
     const int wtile = (int)(task - chunk_id * n_wtiles);
-    const Chunk ch = chunks[chunk_id];                                      // scalar load
+    // Equal-length chunk tables of a single parameter set are addressed arithmetically: the first record load
+    // then does not wait behind a descriptor load (three dependent memory latencies at wave start become one).
+    Chunk ch;
+    if (uniform_len > 0) {
+        ch.begin = chunk_id * uniform_len;
+        const int64_t left = n_records - ch.begin;
+        ch.count = (int32_t)(left < uniform_len ? left : uniform_len);
+        ch.pset = 0;
+    } else {
+        ch = chunks[chunk_id];                                               // scalar load
+    }
     const int64_t w_raw = (int64_t)wtile * kWave + lane;
     const bool active = w_raw < n_walkers;
     const int64_t w_idx = active ? w_raw : n_walkers - 1;                   // idle lanes shadow the last walker
@@ -209,35 +220,38 @@ __global__ __launch_bounds__(kBlock) void per_star_kernel(const T* __restrict__ 
 
 template <int MODEL, bool FREE, class T, class A, bool FAST>
 hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, int64_t n_chunks, const void* wpar,
-                      double* partials, int64_t n_walkers) {
+                      double* partials, int64_t n_walkers, int uniform_len, int64_t n_records) {
     const int n_wtiles = (int)((n_walkers + kWave - 1) / kWave);
     const int64_t n_tasks = n_chunks * n_wtiles;
     const int64_t grid = (n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST>), dim3((unsigned)grid), dim3(kBlock), 0, s,
-                       (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks);
+                       (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,
+                       uniform_len, n_records);
     return hipGetLastError();
 }
 
 template <int MODEL, bool FREE>
 hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* records, const Chunk* chunks,
                             int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers) {
+    const int uniform_len = sh.uniform_len;
+    const int64_t n_records = sh.n_records;
     switch (sh.precision) {
         case 0:
             if (sh.fast)
                 return launch_one<MODEL, FREE, double, double, true>(s, records, chunks, n_chunks, wpar, partials,
-                                                                     n_walkers);
-            return launch_one<MODEL, FREE, double, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
+                                                                     n_walkers, uniform_len, n_records);
+            return launch_one<MODEL, FREE, double, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records);
         case 1:
             if (sh.fast && bg_kind(MODEL) == BG_NONE)
                 return launch_one<MODEL, FREE, float, float, bg_kind(MODEL) == BG_NONE>(s, records, chunks, n_chunks, wpar,
-                                                                                       partials, n_walkers);
-            return launch_one<MODEL, FREE, float, float, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
+                                                                                       partials, n_walkers, uniform_len, n_records);
+            return launch_one<MODEL, FREE, float, float, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records);
         case 2:
             if (sh.fast && bg_kind(MODEL) == BG_NONE)
                 return launch_one<MODEL, FREE, float, double, bg_kind(MODEL) == BG_NONE>(s, records, chunks, n_chunks, wpar,
-                                                                                        partials, n_walkers);
-            return launch_one<MODEL, FREE, float, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers);
+                                                                                        partials, n_walkers, uniform_len, n_records);
+            return launch_one<MODEL, FREE, float, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records);
     }
     return hipErrorInvalidValue;
 }
