@@ -21,6 +21,7 @@
 
 #include "../../include/mcd.h"
 #include "mcd_internal.h"
+#include "mcd_guard.h"
 #include "mcd_math.h"
 
 namespace {
@@ -142,11 +143,7 @@ struct mcd_catalog {
     int64_t n_psets = 1;
     std::vector<int64_t> bin_offsets;  // [n_psets + 1], indices into this process' stars
     std::vector<Shard> shards;
-    // range statistics for the fast-path guard
-    double e2_min = 0, e2_max = 0, v_abs_max = 0;
-    double rho_min = 0, rho_max = 0;
-    bool stats_finite = true;
-    bool extras_ok = true;             // background columns inside the fast-path ranges
+    mcd::CatalogStats stats;           // range statistics for the fast-path guard (mcd_guard.h)
     // options
     bool timing = false;
     bool timing_all = false;           // keep an event pair for every launch (measurement harness)
@@ -273,77 +270,9 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     return MCD_OK;
 }
 
-// Fast paths (f64 only) are valid while their intermediate products stay far from over/underflow.
-//   CONST   (fraction tree over 8 stars + log product): 2^-60 <= verr^2 + sigma^2 <= 2^60, |v - v_los| < 2^58
-//   BGFIXED / BGGAUSS (rsqrt + one exp + log product):  2^-200 <= norm <= 2^200, |v - v_los|^2 / norm <= 1.6e9, finite columns,
-//            lnlike_bg > -1e5, 0 <= pmember <= 1;  density >= 0, f_back >= 0, 2^-100 <= density + f_back <= 2^100
-// Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
-// expressions term by term.
 bool fast_guard(const mcd_catalog* cat, const double* params, int64_t n_rows) {
     if (!cat->allow_fast) return false;
-    if (!cat->stats_finite || n_rows == 0) return false;
-    const bool f32 = cat->precision != MCD_F64;
-    if (f32 && mcd::bg_kind(cat->model) != mcd::BG_NONE) return false;      // f32 mixtures use the plain kernels
-    const int k = cat->k;
-    const bool prof = mcd::is_profile(cat->model);
-    const int bg = mcd::bg_kind(cat->model);
-    const int ix = prof ? 3 : 2, iy = prof ? 4 : 3;
-    const double inf = std::numeric_limits<double>::infinity();
-    double s2_min = inf, s2_max = 0.0, amp = 0.0, sb2_min = inf, sb2_max = 0.0, f_min = inf, f_max = 0.0;
-    double len_min = inf, len_max = 0.0;                       // a and r_peak of the profile models
-    for (int64_t i = 0; i < n_rows; ++i) {
-        const double* p = params + i * k;
-        const double s2 = p[1] * p[1];
-        double a = std::fabs(p[0]) + std::fabs(p[ix]) + std::fabs(p[iy]);
-        if (prof) {
-            if (!(std::isfinite(p[2]) && std::isfinite(p[5]))) return false;
-            len_min = std::min(len_min, std::min(p[2], p[5]));
-            len_max = std::max(len_max, std::max(p[2], p[5]));
-        }
-        if (bg == mcd::BG_GAUSS) {
-            const double sb2 = p[k - 2] * p[k - 2];
-            a = std::max(a, std::fabs(p[k - 3]));
-            if (!std::isfinite(sb2)) return false;
-            sb2_min = std::min(sb2_min, sb2); sb2_max = std::max(sb2_max, sb2);
-        }
-        if (bg == mcd::BG_GAUSS || bg == mcd::BG_FIXED_DENSITY) {
-            const double f = p[k - 1];
-            if (!std::isfinite(f)) return false;
-            f_min = std::min(f_min, f); f_max = std::max(f_max, f);
-        }
-        if (cat->free_centre) {
-            const int ic = prof ? 6 : 4;
-            if (!(std::isfinite(p[ic]) && std::isfinite(p[ic + 1]))) return false;
-        }
-        if (!(std::isfinite(s2) && std::isfinite(a))) return false;
-        s2_min = std::min(s2_min, s2);
-        s2_max = std::max(s2_max, s2);
-        amp = std::max(amp, a);
-    }
-    // |v - v_los| <= |v| + |v_sys| + |v_max| (the Lynden-Bell factor 2 r r_peak / (r^2 + r_peak^2) is <= 1)
-    const double d_max = cat->v_abs_max + amp;
-    if (!(d_max <= std::ldexp(1.0, 58))) return false;
-    // sigma_los of the profile models decays to 0 at large r: only verr^2 bounds the variance from below
-    const double n_min = cat->e2_min + (prof ? 0.0 : s2_min), n_max = cat->e2_max + s2_max;
-    if (prof && !(len_min >= std::ldexp(1.0, -100) && len_max <= std::ldexp(1.0, 100))) return false;   // a, r_peak > 0
-    if (bg == mcd::BG_NONE) {
-        if (f32)      // 4-star tree in f32: DEN <= 2^60, NUM <= 2^77
-            return (n_min >= std::ldexp(1.0, -15)) && (n_max <= std::ldexp(1.0, 15)) && (d_max <= std::ldexp(1.0, 15)) &&
-                   (!prof || (len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20)));
-        return (n_min >= std::ldexp(1.0, -60)) && (n_max <= std::ldexp(1.0, 60));
-    }
-    const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
-    if (!((n_min >= lo) && (n_max <= hi))) return false;
-    // exponent arguments stay below 1e9 in magnitude: (|v| + |v_los|)^2 / norm_min <= 1.6e9
-    if (!(d_max * d_max <= 1.6e9 * n_min)) return false;
-    if (!cat->extras_ok) return false;
-    if (bg == mcd::BG_GAUSS) {
-        if (!((cat->e2_min + sb2_min >= lo) && (cat->e2_max + sb2_max <= hi))) return false;
-        if (!(d_max * d_max <= 1.6e9 * (cat->e2_min + sb2_min))) return false;
-    }
-    if (bg == mcd::BG_GAUSS || bg == mcd::BG_FIXED_DENSITY)
-        return f_min >= 0.0 && (cat->rho_min + f_min >= std::ldexp(1.0, -100)) && (cat->rho_max + f_max <= std::ldexp(1.0, 100));
-    return true;
+    return mcd::fast_guard(cat->stats, cat->model, cat->free_centre, cat->precision != MCD_F64, cat->k, params, n_rows);
 }
 
 int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, bool zero_copy) {
@@ -646,40 +575,8 @@ static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::uni
         cat->bin_offsets = {0, d->n_stars};
     }
 
-    // range statistics for the fast-path guard (runner.py:261: norm = verr*verr + sigma*sigma)
-    double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
-    bool finite = true;
-    for (int64_t i = 0; i < d->n_stars; ++i) {
-        const double e2 = d->verr[i] * d->verr[i];
-        const double av = std::fabs(d->v[i]);
-        if (!(std::isfinite(e2) && std::isfinite(av))) { finite = false; continue; }
-        e2_min = std::min(e2_min, e2);
-        e2_max = std::max(e2_max, e2);
-        v_abs = std::max(v_abs, av);
-    }
-    if (d->n_stars == 0) e2_min = 0.0;
-    cat->e2_min = e2_min; cat->e2_max = e2_max; cat->v_abs_max = v_abs; cat->stats_finite = finite;
-    {
-        bool ok = true;
-        double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
-        for (int64_t i = 0; i < d->n_stars && ok; ++i) {
-            if (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY) {
-                const double b = d->lnlike_bg[i];
-                if (!(std::isfinite(b) && b > -1.0e5 && b < 1.0e5)) ok = false;
-            }
-            if (bgk == mcd::BG_FIXED) {
-                const double pm = d->pmember[i];
-                if (!(pm >= 0.0 && pm <= 1.0)) ok = false;
-            }
-            if (bgk == mcd::BG_GAUSS || bgk == mcd::BG_FIXED_DENSITY) {
-                const double rho = d->density[i];
-                if (!(std::isfinite(rho) && rho >= 0.0)) ok = false;
-                r_min = std::min(r_min, rho); r_max = std::max(r_max, rho);
-            }
-        }
-        if (d->n_stars == 0) r_min = 0.0;
-        cat->extras_ok = ok; cat->rho_min = r_min; cat->rho_max = r_max;
-    }
+    // range statistics for the fast-path guard
+    cat->stats = mcd::compute_stats(d->n_stars, d->v, d->verr, d->lnlike_bg, d->pmember, d->density, bgk);
 
     // contiguous star shards, one per device of this process
     const int n_dev = (int)ctx->slots.size();

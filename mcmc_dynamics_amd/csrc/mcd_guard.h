@@ -1,0 +1,131 @@
+// mcd_guard.h -- host-side range guard that decides, per call, whether the fast kernel formulations may be used.
+// Shared by the C-ABI (mcd_api.hip) and by the CPU test harness (tests/emul), so that the randomized tests exercise
+// exactly the condition the library applies.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+
+#include "mcd_math.h"
+
+namespace mcd {
+
+// Range statistics of one catalogue, gathered at upload.
+struct CatalogStats {
+    double e2_min = 0, e2_max = 0, v_abs_max = 0;   // verr^2 range, max |v|
+    double rho_min = 0, rho_max = 0;                // density range (BG_GAUSS / BG_FIXED_DENSITY)
+    bool stats_finite = true;                       // v, verr all finite
+    bool extras_ok = true;                          // background columns inside the fast-path ranges
+};
+
+// Gathered once at upload from the host columns (runner.py:261: norm = verr*verr + sigma*sigma).
+inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr, const double* lnbg,
+                                  const double* pmember, const double* density, int bg) {
+    CatalogStats st;
+    double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
+    double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
+    bool finite = true, ok = true;
+    for (int64_t i = 0; i < n; ++i) {
+        const double e2 = verr[i] * verr[i];
+        const double av = std::fabs(v[i]);
+        if (!(std::isfinite(e2) && std::isfinite(av))) { finite = false; continue; }
+        e2_min = std::min(e2_min, e2);
+        e2_max = std::max(e2_max, e2);
+        v_abs = std::max(v_abs, av);
+    }
+    for (int64_t i = 0; i < n && ok; ++i) {
+        if (bg == BG_FIXED || bg == BG_FIXED_DENSITY) {
+            const double b = lnbg[i];
+            if (!(std::isfinite(b) && b > -1.0e5 && b < 1.0e5)) ok = false;
+        }
+        if (bg == BG_FIXED) {
+            const double pm = pmember[i];
+            if (!(pm >= 0.0 && pm <= 1.0)) ok = false;
+        }
+        if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) {
+            const double rho = density[i];
+            if (!(std::isfinite(rho) && rho >= 0.0)) ok = false;
+            r_min = std::min(r_min, rho);
+            r_max = std::max(r_max, rho);
+        }
+    }
+    if (n == 0) { e2_min = 0.0; r_min = 0.0; }
+    st.e2_min = e2_min; st.e2_max = e2_max; st.v_abs_max = v_abs; st.stats_finite = finite;
+    st.extras_ok = ok; st.rho_min = r_min; st.rho_max = r_max;
+    return st;
+}
+
+// Fast paths (f64 only) are valid while their intermediate products stay far from over/underflow.
+//   CONST   (fraction tree over 8 stars + log product): 2^-60 <= verr^2 + sigma^2 <= 2^60, |v - v_los| < 2^58
+//   BGFIXED / BGGAUSS (rsqrt + one exp + log product):  2^-200 <= norm <= 2^200, |v - v_los|^2 / norm <= 1.6e9, finite columns,
+//            lnlike_bg > -1e5, 0 <= pmember <= 1;  density >= 0, f_back >= 0, 2^-100 <= density + f_back <= 2^100
+// Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
+// expressions term by term.
+inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
+                       int64_t n_rows) {
+    if (!st.stats_finite || n_rows == 0) return false;
+    if (f32 && bg_kind(model) != BG_NONE) return false;      // f32 mixtures use the plain kernels
+    const bool prof = is_profile(model);
+    const int bg = bg_kind(model);
+    const int ix = prof ? 3 : 2, iy = prof ? 4 : 3;
+    const double inf = std::numeric_limits<double>::infinity();
+    double s2_min = inf, s2_max = 0.0, amp = 0.0, sb2_min = inf, sb2_max = 0.0, f_min = inf, f_max = 0.0;
+    double len_min = inf, len_max = 0.0;                       // a and r_peak of the profile models
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const double* p = params + i * k;
+        const double s2 = p[1] * p[1];
+        double a = std::fabs(p[0]) + std::fabs(p[ix]) + std::fabs(p[iy]);
+        if (prof) {
+            if (!(std::isfinite(p[2]) && std::isfinite(p[5]))) return false;
+            len_min = std::min(len_min, std::min(p[2], p[5]));
+            len_max = std::max(len_max, std::max(p[2], p[5]));
+        }
+        if (bg == BG_GAUSS) {
+            const double sb2 = p[k - 2] * p[k - 2];
+            a = std::max(a, std::fabs(p[k - 3]));
+            if (!std::isfinite(sb2)) return false;
+            sb2_min = std::min(sb2_min, sb2); sb2_max = std::max(sb2_max, sb2);
+        }
+        if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) {
+            const double f = p[k - 1];
+            if (!std::isfinite(f)) return false;
+            f_min = std::min(f_min, f); f_max = std::max(f_max, f);
+        }
+        if (free_centre) {
+            const int ic = prof ? 6 : 4;
+            if (!(std::isfinite(p[ic]) && std::isfinite(p[ic + 1]))) return false;
+        }
+        if (!(std::isfinite(s2) && std::isfinite(a))) return false;
+        s2_min = std::min(s2_min, s2);
+        s2_max = std::max(s2_max, s2);
+        amp = std::max(amp, a);
+    }
+    // |v - v_los| <= |v| + |v_sys| + |v_max| (the Lynden-Bell factor 2 r r_peak / (r^2 + r_peak^2) is <= 1)
+    const double d_max = st.v_abs_max + amp;
+    if (!(d_max <= std::ldexp(1.0, 58))) return false;
+    // sigma_los of the profile models decays to 0 at large r: only verr^2 bounds the variance from below
+    const double n_min = st.e2_min + (prof ? 0.0 : s2_min), n_max = st.e2_max + s2_max;
+    if (prof && !(len_min >= std::ldexp(1.0, -100) && len_max <= std::ldexp(1.0, 100))) return false;   // a, r_peak > 0
+    if (bg == BG_NONE) {
+        if (f32)      // 4-star tree in f32: DEN <= 2^60, NUM <= 2^77
+            return (n_min >= std::ldexp(1.0, -15)) && (n_max <= std::ldexp(1.0, 15)) && (d_max <= std::ldexp(1.0, 15)) &&
+                   (!prof || (len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20)));
+        return (n_min >= std::ldexp(1.0, -60)) && (n_max <= std::ldexp(1.0, 60));
+    }
+    const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
+    if (!((n_min >= lo) && (n_max <= hi))) return false;
+    // exponent arguments stay below 1e9 in magnitude: (|v| + |v_los|)^2 / norm_min <= 1.6e9
+    if (!(d_max * d_max <= 1.6e9 * n_min)) return false;
+    if (!st.extras_ok) return false;
+    if (bg == BG_GAUSS) {
+        if (!((st.e2_min + sb2_min >= lo) && (st.e2_max + sb2_max <= hi))) return false;
+        if (!(d_max * d_max <= 1.6e9 * (st.e2_min + sb2_min))) return false;
+    }
+    if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY)
+        return f_min >= 0.0 && (st.rho_min + f_min >= std::ldexp(1.0, -100)) && (st.rho_max + f_max <= std::ldexp(1.0, 100));
+    return true;
+}
+
+}  // namespace mcd

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <vector>
 
+#include "mcd_guard.h"
 #include "mcd_math.h"
 
 using namespace mcd;
@@ -64,4 +65,12 @@ extern "C" int emul_per_star(int model, int free_centre, int mode, int64_t n, co
     FOR_ALL(1) FOR_ALL(2) FOR_ALL(4) FOR_ALL(5)
 #undef CASE
     return -1;
+}
+
+// the library's own range guard (csrc/mcd_guard.h) on raw host columns and a C-ABI-ordered parameter table
+extern "C" int emul_fast_guard(int model, int free_centre, int f32, int64_t n, const double* v, const double* verr,
+                               const double* lnbg, const double* pmember, const double* density, int k,
+                               const double* params, int64_t n_rows) {
+    const CatalogStats st = compute_stats(n, v, verr, lnbg, pmember, density, bg_kind(model));
+    return fast_guard(st, model, free_centre != 0, f32 != 0, k, params, n_rows) ? 1 : 0;
 }

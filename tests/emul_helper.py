@@ -22,7 +22,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        deps = [SRC, os.path.join(INC, "mcd_math.h")]
+        deps = [SRC, os.path.join(INC, "mcd_math.h"), os.path.join(INC, "mcd_guard.h")]
         if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", INC, SRC,
                             "-o", OUT], check=True)
@@ -121,3 +121,15 @@ def per_star(cat, params_row, model, centre, mode):
                              out.ctypes.data)
     assert rc == 0
     return out
+
+
+def fast_guard(cat, params, model, centre, f32=False):
+    """The library's per-call range guard (csrc/mcd_guard.h) for this catalogue and C-ABI parameter table."""
+    lib().emul_fast_guard.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 5 + \
+        [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
+    cols = [np.ascontiguousarray(cat[k], dtype=np.float64) if k in cat else None
+            for k in ("v", "verr", "lnlike_bg", "pmember", "density")]
+    params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+    ptr = [c.ctypes.data if c is not None else None for c in cols]
+    return bool(lib().emul_fast_guard(model, int(centre is None), int(f32), len(cat["v"]), *ptr, params.shape[1],
+                                      params.ctypes.data, params.shape[0]))

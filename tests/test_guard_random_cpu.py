@@ -1,0 +1,93 @@
+"""Randomised check of the fast-path range guard (csrc/mcd_guard.h) together with the fast formulations
+(csrc/mcd_math.h), both compiled for the host: over catalogues and walkers spanning many orders of magnitude,
+whenever the guard admits the fast path its result must agree with the plain (reference-literal) path; and the guard
+must refuse the inputs the fast paths cannot represent."""
+import numpy as np
+import pytest
+
+import emul_helper as emul
+from conftest import rel_err
+
+CENTRE = (56.345, -26.675)
+MODELS = {0: 4, 1: 4, 2: 7, 3: 6, 4: 9, 5: 7}          # model id -> K (fixed centre)
+
+
+def random_case(rng, model, n=300, w=6):
+    scale_v = 10.0 ** rng.uniform(-1, 3.5)               # velocity scale 0.1 .. 3000 km/s
+    scale_e = 10.0 ** rng.uniform(-3, 2.5)               # error scale
+    sep = np.abs(rng.normal(0, 2.0 / 60.0, n))
+    th = rng.uniform(-np.pi, np.pi, n)
+    cat = {"ra": CENTRE[0] + sep * np.cos(th) / np.cos(np.radians(CENTRE[1])), "dec": CENTRE[1] + sep * np.sin(th),
+           "v": rng.normal(0, scale_v, n), "verr": scale_e * rng.lognormal(0, 1.0, n)}
+    cat["v"][:3] *= 50.0                                  # a few gross outliers
+    cat["density"] = np.clip(rng.random(n), 0.0, 1.0)
+    cat["density"][0] = 0.0
+    cat["pmember"] = np.clip(rng.random(n) * 1.2 - 0.1, 0.0, 1.0)     # includes exact 0 and 1
+    cat["lnlike_bg"] = -0.5 * (cat["v"] / (4 * scale_v)) ** 2 - np.log(4 * scale_v) - rng.uniform(0, 3, n)
+    sig = scale_v * 10.0 ** rng.uniform(-2, 1, w)
+    cols = [rng.normal(0, scale_v, w), sig]
+    if model >= 3:
+        cols.append(10.0 ** rng.uniform(-1, 3, w))        # a [arcsec]
+    cols += [rng.normal(0, scale_v, w), rng.normal(0, scale_v, w)]
+    if model >= 3:
+        cols.append(10.0 ** rng.uniform(-1, 3, w))        # r_peak
+    if model in (2, 4):
+        cols += [rng.normal(0, scale_v, w), 4 * scale_v * 10.0 ** rng.uniform(-1, 1, w), rng.random(w)]
+    if model == 5:
+        cols.append(rng.random(w))
+    return cat, np.stack(cols, axis=1)
+
+
+@pytest.mark.parametrize("model", sorted(MODELS))
+def test_guarded_fast_path_agrees_with_plain_path(model):
+    rng = np.random.default_rng(100 + model)
+    admitted = refused = 0
+    for trial in range(60):
+        cat, params = random_case(rng, model)
+        assert params.shape[1] == MODELS[model]
+        plain = emul.loglike(cat, params, model, CENTRE, 0, chunk_len=64)
+        if not emul.fast_guard(cat, params, model, CENTRE):
+            refused += 1
+            continue
+        admitted += 1
+        fast = emul.loglike(cat, params, model, CENTRE, 1, chunk_len=64)
+        both = np.isfinite(plain) & np.isfinite(fast)
+        assert np.array_equal(np.isfinite(plain), np.isfinite(fast)), (trial, plain, fast)
+        assert rel_err(fast[both], plain[both]) < 1e-11, (trial, plain, fast)
+    assert admitted >= 30, (admitted, refused)            # the guard must not be so strict that it is never used
+
+
+def test_guard_refuses_what_the_fast_paths_cannot_represent():
+    rng = np.random.default_rng(7)
+    cat, params = random_case(rng, 0)
+    assert emul.fast_guard(cat, params, 0, CENTRE)
+    bad = params.copy()
+    bad[0, 1] = np.nan
+    assert not emul.fast_guard(cat, bad, 0, CENTRE)                       # NaN parameter
+    bad = params.copy()
+    bad[0, 1] = 1e40
+    assert not emul.fast_guard(cat, bad, 0, CENTRE)                       # sigma^2 beyond 2^60
+    zero = dict(cat, verr=cat["verr"].copy())
+    zero["verr"][5] = 0.0
+    z = params.copy()
+    z[:, 1] = 0.0
+    assert not emul.fast_guard(zero, z, 0, CENTRE)                        # norm can be exactly 0
+    assert emul.fast_guard(zero, params, 0, CENTRE)                       # ... but not when sigma > 0
+    inf_cat = dict(cat, v=cat["v"].copy())
+    inf_cat["v"][0] = np.inf
+    assert not emul.fast_guard(inf_cat, params, 0, CENTRE)                # non-finite data
+    cat1, p1 = random_case(rng, 1)
+    assert emul.fast_guard(cat1, p1, 1, CENTRE)
+    far = dict(cat1, lnlike_bg=cat1["lnlike_bg"].copy())
+    far["lnlike_bg"][3] = -2e5
+    assert not emul.fast_guard(far, p1, 1, CENTRE)                        # background lnL outside +-1e5
+    cat2, p2 = random_case(rng, 2)
+    neg = p2.copy()
+    neg[0, -1] = -0.1
+    assert not emul.fast_guard(cat2, neg, 2, CENTRE)                      # f_back < 0 (prior would reject it anyway)
+    cat3, p3 = random_case(rng, 3)
+    a0 = p3.copy()
+    a0[0, 2] = 0.0
+    assert not emul.fast_guard(cat3, a0, 3, CENTRE)                       # a = 0: plain path reproduces the reference's limit
+    assert not emul.fast_guard(cat1, p1, 1, CENTRE, f32=True)             # f32 mixtures always plain
+    assert emul.fast_guard(cat, params, 0, CENTRE, f32=True) in (True, False)
