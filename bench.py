@@ -191,6 +191,9 @@ def main():
             all_cores = {"error": repr(exc)}
 
     from mcmc_dynamics_amd import _native as native
+    n_visible = int(os.environ.get("MCD_VISIBLE_DEVICES", "0")) or None      # testing aid: fold ranks onto fewer devices
+    if n_visible:
+        local_rank = local_rank % n_visible
     dist = None
     if world > 1:
         import torch.distributed as dist           # host-side rendezvous only (gloo); the data path is RCCL in the library

@@ -1,4 +1,19 @@
-from .runner import Runner  # noqa: F401
-from .constant import ConstantFit, ConstantFitGB  # noqa: F401
-from .model import ModelFit, ModelFitGB, ModelFitConstantBackground  # noqa: F401
-from .binned import BinnedConstantFit  # noqa: F401
+"""Analysis classes: the reference's ``Runner`` hierarchy with the per-star likelihood arithmetic moved to the GPU.
+
+================================  =====================================================================
+class                             reference counterpart
+================================  =====================================================================
+``Runner``                        ``mcmc_dynamics/analysis/runner.py`` (posterior API + MCMC driver)
+``ConstantFit``, ``ConstantFitGB``  ``analysis/constant.py`` (constant rotation + dispersion, Gaussian background)
+``ModelFit``, ``ModelFitGB``,     ``analysis/model.py`` (Lynden-Bell rotation curve + Plummer dispersion profile)
+``ModelFitConstantBackground``
+``BinnedConstantFit``             the per-radial-bin loop of ``bin/run_tests.py:75-124`` as ONE batched posterior
+================================  =====================================================================
+"""
+from .binned import BinnedConstantFit
+from .constant import ConstantFit, ConstantFitGB
+from .model import ModelFit, ModelFitConstantBackground, ModelFitGB
+from .runner import Runner
+
+__all__ = ["Runner", "ConstantFit", "ConstantFitGB", "ModelFit", "ModelFitGB", "ModelFitConstantBackground",
+           "BinnedConstantFit"]
