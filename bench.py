@@ -27,7 +27,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip table)
-F64_VALU_PEAK_GOPS = 256 * 4 * 16 * 2.4    # lane-ops/ns: 256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2.4 GHz
+# f64 VALU issue model (the resource that actually binds these kernels):
+#   slots per term of the fast-path inner loops from the gfx950 ISA (tools/isa_mix.py), one slot = one f64 wave-instruction
+#   per SIMD = 2.33 ns on the fully occupied chip (tools/valu_rate_probe.hip).
+VALU_SLOTS_PER_TERM = {"const": 9.11, "bgfixed": 39.27, "bggauss": 61.55}
+VALU_SLOT_NS = 2.33
+N_SIMD = 256 * 4
 
 WORKLOADS = {
     # name: (description, stars per GPU, walkers, model, algorithmic bytes per term, config number)
@@ -361,6 +366,13 @@ def main():
                      "note": "streaming-model bytes (each walker's sum reads every star record once, SURVEY 8(d)); "
                              "the kernel reuses one scalar record load for 64 walkers, so frac > 1 means register "
                              "reuse and the binding resource is f64 VALU issue, not HBM"},
+        "valu_f64_model": None if args.precision != "f64" else {
+            "slots_per_term": VALU_SLOTS_PER_TERM[model], "slot_ns": VALU_SLOT_NS,
+            "predicted_kernel_us": VALU_SLOTS_PER_TERM[model] * VALU_SLOT_NS * (local_terms / 64) / N_SIMD * 1e-3,
+            "measured_over_predicted": kernel_s * 1e6 / (VALU_SLOTS_PER_TERM[model] * VALU_SLOT_NS * (local_terms / 64) / N_SIMD * 1e-3),
+            "note": "the kernel is bound by f64 vector-instruction issue; predicted = instruction mix of the inner loop "
+                    "priced at the measured issue rate of a fully occupied MI355X (prologue, final log and launch tail "
+                    "not included)"},
         "hbm_algorithmic_GBps": value * bytes_per_term / 1e9,
         "hbm_roofline_frac": value * bytes_per_term / 1e9 / HBM_PEAK_GBPS / world,
         "sync_call_terms_per_s": local_terms * world / sync_call,
