@@ -30,7 +30,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, c
 # f64 VALU issue model (the resource that actually binds these kernels):
 #   slots per term of the fast-path inner loops from the gfx950 ISA (tools/isa_mix.py), one slot = one f64 wave-instruction
 #   per SIMD = 2.33 ns on the fully occupied chip (tools/valu_rate_probe.hip).
-VALU_SLOTS_PER_TERM = {"const": 9.11, "bgfixed": 39.27, "bggauss": 61.55}
+VALU_SLOTS_PER_TERM = {"const": 9.11, "bgfixed": 39.27, "bggauss": 61.55, "profile": 27.91}
 VALU_SLOT_NS = 2.33
 N_SIMD = 256 * 4
 
@@ -45,6 +45,8 @@ WORKLOADS = {
                 32, 3),
     "c4": ("C4: 1e7 synthetic stars sharded over the GPUs (strong scaling), rotation+dispersion", 10000000, 256,
            "const", 32, 4),
+    "m1": ("next-row ModelFit: 1e6 synthetic stars x 256 walkers, Lynden-Bell rotation curve + Plummer dispersion "
+           "profile (analysis/model.py), fixed centre", 1000000, 256, "profile", 32, 3),
     "c5": ("C5: radial-binned dispersion profile (make_radial_bins nstars=1000, dlogr=0.05), 1e6 synthetic stars x 512 "
            "walkers per bin, rotation+dispersion, one segmented launch for all bins", 1000000, 512, "const", 32, 5),
 }
@@ -77,6 +79,8 @@ def build_catalog(native, ctx, synthetic, oracle, cat, model, precision="f64", b
         lnbg = Gaussian(synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])(cat["v"], cat["verr"])
         return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST_BGFIXED,
                               centre=centre, lnlike_bg=lnbg, pmember=cat["pmember"])
+    if model == "profile":
+        return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_PROFILE, centre=centre)
     return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST_BGGAUSS,
                           centre=centre, density=cat["density"])
 
@@ -95,6 +99,8 @@ def cpu_baseline(cat, pos, model, budget_s):
         if model == "bggauss":
             return oracle.faithful_constant_gb_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
                                                       row[4], row[5], row[6])
+        if model == "profile":          # C-ABI column order: v_sys, sigma_max, a, v_maxx, v_maxy, r_peak
+            return oracle.faithful_model_lnlike(cat, row[0], row[1], row[2], row[3], row[4], row[5], centre[0], centre[1])
         return oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
                                                lnlike_background=lnbg, pmember=cat.get("pmember") if lnbg is not None else None)
 
@@ -251,6 +257,11 @@ def main():
         truth = box[0]
     names = ["v_sys", "sigma_max", "v_maxx", "v_maxy"] + (["v_back", "sigma_back", "f_back"] if model == "bggauss" else [])
     pos = synthetic.make_walkers(n_walkers, names, truth, config=config)
+    if model == "profile":              # insert a (30 arcsec) and r_peak (60 arcsec) balls: run_tests.py:36-37
+        rng_m = np.random.default_rng(synthetic.WALKER_SEED_BASE + 100 + config)
+        a_col = 30.0 * (1.0 + 0.05 * rng_m.normal(size=n_walkers))
+        rp_col = 60.0 * (1.0 + 0.05 * rng_m.normal(size=n_walkers))
+        pos = np.column_stack([pos[:, 0], pos[:, 1], a_col, pos[:, 2], pos[:, 3], rp_col])
 
     bin_offsets, n_bins = None, 1
     if args.workload == "c5":
@@ -304,7 +315,7 @@ def main():
     # sampler-driven end-to-end rate (1 GPU only): the built-in stretch move makes two blocking calls of W/2
     # proposals per step, exactly the batching emcee's default move produces (hard parts)
     mcmc = None
-    if world == 1 and n_bins == 1 and not args.no_mcmc:
+    if world == 1 and n_bins == 1 and not args.no_mcmc and model != "profile":
         import logging
         from mcmc_dynamics_amd import DataReader, Gaussian
         from mcmc_dynamics_amd.analysis import ConstantFit, ConstantFitGB

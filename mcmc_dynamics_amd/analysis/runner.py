@@ -421,11 +421,12 @@ class Runner(object):
             figure.savefig(filename)
         return figure
 
-    def sample_chain(self, chain, n_burn, n_samples):
-        """Random parameter draws from the post-burn-in chain (runner.py:820-850)."""
-        flat = np.asarray(chain)[:, n_burn:, :].reshape(-1, self.n_fitted_parameters)
-        idx = np.random.randint(flat.shape[0], size=n_samples)
-        return flat[idx]
+    def sample_chain(self, chain, n_burn, n_samples=1):
+        """``n_samples`` random parameter sets from the post-burn-in chain, each as the dictionary
+        ``fetch_parameter_values`` returns (runner.py:820-850)."""
+        flat = np.reshape(np.asarray(chain)[:, n_burn:], (-1, np.shape(chain)[-1]))
+        indices = np.random.randint(0, flat.shape[0], (n_samples,))
+        return [self.fetch_parameter_values(row) for row in flat[indices]]
 
     # ------------------------------------------------------------------ device catalogue
     # Sub-classes set `_model_id` and the ordered (name, canonical unit) columns of the kernel's parameter
