@@ -375,7 +375,7 @@ int enqueue(mcd_catalog* cat) {
         WorkSet& w0 = cat->shards[0].work.at(W);
         const int64_t n_wtiles = (W + 63) / 64;
         cat->last_chunks = w0.n_chunks;
-        cat->last_grid = (w0.n_chunks * n_wtiles + 3) / 4;
+        cat->last_grid = n_wtiles <= 4 ? (w0.n_chunks * n_wtiles + 3) / 4 : (w0.n_chunks + 7) / 8 * 8 * ((n_wtiles + 3) / 4);
     }
     return MCD_OK;
 }

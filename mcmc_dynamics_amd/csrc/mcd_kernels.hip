@@ -124,10 +124,26 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
     constexpr int ND = record_doubles(MODEL, FREE);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave;      // wave-uniform
-    if (task >= n_tasks) return;
-    const int64_t chunk_id = task / n_wtiles;
-    const int wtile = (int)(task - chunk_id * n_wtiles);
+    int64_t chunk_id;
+    int wtile;
+    if (n_wtiles <= kWavesPerBlock) {
+        // <= 256 walkers: consecutive waves share a chunk, so every chunk is read by one workgroup (one CU, one XCD)
+        const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave;  // wave-uniform
+        if (task >= n_tasks) return;
+        chunk_id = task / n_wtiles;
+        wtile = (int)(task - chunk_id * n_wtiles);
+    } else {
+        // > 256 walkers: a chunk needs m = ceil(n_wtiles / 4) workgroups.  Workgroups are dealt round-robin over the
+        // 8 XCDs, so workgroups b and b + 8 share an XCD (and its L2): within a group of 8 m workgroups, workgroup j
+        // takes chunk j % 8 and walker-tile quartet j / 8 -- all m readers of a chunk sit on one XCD and the chunk is
+        // fetched from HBM once.  (Placement only affects traffic, never results.)
+        const int m = (n_wtiles + kWavesPerBlock - 1) / kWavesPerBlock;
+        const int64_t group = blockIdx.x / (8 * m);
+        const int j = (int)(blockIdx.x - group * (8 * m));
+        chunk_id = group * 8 + (j & 7);
+        wtile = (j >> 3) * kWavesPerBlock + wave;
+        if (chunk_id >= n_chunks || wtile >= n_wtiles) return;
+    }
     // Equal-length chunk tables of a single parameter set are addressed arithmetically: the first record load
     // then does not wait behind a descriptor load (three dependent memory latencies at wave start become one).
     Chunk ch;
@@ -223,7 +239,9 @@ hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, i
                       double* partials, int64_t n_walkers, int uniform_len, int64_t n_records) {
     const int n_wtiles = (int)((n_walkers + kWave - 1) / kWave);
     const int64_t n_tasks = n_chunks * n_wtiles;
-    const int64_t grid = (n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    int64_t grid = (n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (n_wtiles > kWavesPerBlock)                         // XCD-aware grouping, see loglike_kernel
+        grid = (n_chunks + 7) / 8 * 8 * ((n_wtiles + kWavesPerBlock - 1) / kWavesPerBlock);
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST>), dim3((unsigned)grid), dim3(kBlock), 0, s,
                        (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,

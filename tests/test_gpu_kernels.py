@@ -161,7 +161,7 @@ def test_ragged_shapes(native, ctx):
     """W not a multiple of the 64-lane walker tile, N not a multiple of the 8-star group, tiny N."""
     from mcmc_dynamics_amd import synthetic
     from oracle import lnprob_numpy as oracle
-    for n, w in ((1, 1), (7, 3), (63, 65), (1001, 130), (4097, 64)):
+    for n, w in ((1, 1), (7, 3), (63, 65), (1001, 130), (4097, 64), (3000, 300), (2500, 512), (900, 1000)):
         c, centre = _synthetic(n, 2)
         pos = synthetic.make_walkers(w, NAMES4, c["truth"], config=2)
         cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
