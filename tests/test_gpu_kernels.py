@@ -329,3 +329,24 @@ def test_single_stars_background(native, ctx):
                          lnlike_bg=lnbg, pmember=c["pmember"])
     want = oracle.batched_constant_lnlike(c, pos, *centre, lnlike_background=lnbg, pmember=c["pmember"])
     assert rel_err(cat.loglike(pos), want) < RTOL
+
+
+def test_closed_form_known_answer(native, ctx):
+    """SURVEY.md 8(c) known-answer (1): v_max = 0 => lnL = sum -1/2 [log(2 pi (e_i^2 + s^2)) + (v_i - v_sys)^2 / (e_i^2 + s^2)]
+    on three hand-computable stars, through every kernel formulation; and (6): sigma = 0 is accepted by the kernels."""
+    ra, dec = np.array([10.0, 10.01, 9.99]), np.array([0.0, 0.01, -0.01])
+    v, verr = np.array([1.0, -2.0, 0.5]), np.array([1.0, 2.0, 0.5])
+    rows = np.array([[0.25, 3.0, 0.0, 0.0], [-1.0, 0.0, 0.0, 0.0], [0.0, 7.5, 0.0, 0.0]])
+    want = np.array([np.sum(-0.5 * (np.log(2 * np.pi * (verr ** 2 + s ** 2)) + (v - vs) ** 2 / (verr ** 2 + s ** 2)))
+                     for vs, s, _, _ in rows])
+    for fast in (1, 0):
+        cat = native.Catalog(ctx, ra, dec, v, verr, model=native.MODEL_CONST, centre=(10.0, 0.0))
+        cat.set_option("fast_path", fast)
+        assert np.max(np.abs(cat.loglike(rows) - want)) < 1e-13
+        free = native.Catalog(ctx, ra, dec, v, verr, model=native.MODEL_CONST, centre=None)
+        free.set_option("fast_path", fast)
+        assert np.max(np.abs(free.loglike(np.hstack([rows, np.tile([10.0, 0.0], (3, 1))])) - want)) < 1e-13
+    # ModelFit with v_max = 0 and a -> infinity is the constant-dispersion model
+    prof = native.Catalog(ctx, ra, dec, v, verr, model=native.MODEL_PROFILE, centre=(10.0, 0.0))
+    prows = np.column_stack([rows[:, 0], rows[:, 1], np.full(3, 1e12), rows[:, 2], rows[:, 3], np.full(3, 60.0)])
+    assert np.max(np.abs(prof.loglike(prows) - want)) < 1e-9
