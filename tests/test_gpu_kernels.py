@@ -350,3 +350,31 @@ def test_closed_form_known_answer(native, ctx):
     prof = native.Catalog(ctx, ra, dec, v, verr, model=native.MODEL_PROFILE, centre=(10.0, 0.0))
     prows = np.column_stack([rows[:, 0], rows[:, 1], np.full(3, 1e12), rows[:, 2], rows[:, 3], np.full(3, 60.0)])
     assert np.max(np.abs(prof.loglike(prows) - want)) < 1e-9
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 4, 5])
+def test_fast_and_plain_kernels_agree_over_wide_ranges(native, ctx, model):
+    """Device counterpart of tests/test_guard_random_cpu.py: random catalogues / walkers spanning many orders of
+    magnitude (velocity scale 0.1 .. 3000 km/s, errors 1e-3 .. 300 km/s, gross outliers, pmember in {0, 1}, density 0).
+    With the fast path enabled (the library's guard decides per call) and disabled, the results must agree, including
+    which walkers are -inf.  This exercises v_rsq_f64 / v_rcp_f64 + Newton steps on the hardware."""
+    from test_guard_random_cpu import CENTRE, MODELS, random_case
+    rng = np.random.default_rng(500 + model)
+    for trial in range(25):
+        cat, params = random_case(rng, model, n=500, w=70)
+        kw = {}
+        if model == 1:
+            kw = dict(lnlike_bg=cat["lnlike_bg"], pmember=cat["pmember"])
+        elif model in (2, 4):
+            kw = dict(density=cat["density"])
+        elif model == 5:
+            kw = dict(lnlike_bg=cat["lnlike_bg"], density=cat["density"])
+        g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model, centre=CENTRE, **kw)
+        assert g.k == MODELS[model]
+        fast = g.loglike(params)
+        g.set_option("fast_path", 0)
+        plain = g.loglike(params)
+        g.close()
+        assert np.array_equal(np.isfinite(fast), np.isfinite(plain)), (trial, fast, plain)
+        ok = np.isfinite(plain)
+        assert rel_err(fast[ok], plain[ok]) < 1e-11, trial
