@@ -175,6 +175,11 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value);
 /* With "timing" = 2: waits for the device, returns the summed HIP-event duration (ms) of all main-kernel
  * launches on device 0 of this process since the last collect / option change and their number. */
 int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_launches);
+/* Number of batches this catalogue re-evaluated with the plain kernels because a fast mixture kernel met the regime in
+ * which the reference's log-sum-exp (runner.py:282-284) itself runs on denormal numbers -- a star with pmember == 1,
+ * f_back == 0 or density == 0 that lies > 37 sigma from the only remaining component.  Only the literal expression
+ * reproduces the reference's value there; the re-evaluation is automatic and synchronous inside fetch / batch. */
+int64_t mcd_rerun_count(const mcd_catalog* cat);
 /* Launch geometry of the main kernel for the last call: workgroups, walker tile (walkers that
  * reuse one star record load), chunks per parameter set, bytes per star record. */
 int mcd_last_launch_info(const mcd_catalog* cat, int64_t* n_workgroups, int32_t* walker_tile,

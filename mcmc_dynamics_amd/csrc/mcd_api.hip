@@ -106,6 +106,7 @@ struct WorkSet {
     double* m_params = nullptr;        // device view of h_params (zero-copy path of the blocking call)
     double* m_out = nullptr;           // device view of h_out
     bool mapped = false;               // last staging used the zero-copy path: results land in h_out directly
+    double launch_tag = 0.0;           // tag of the last fast-path launch (written to out[n_out] by a kernel that wants a re-run)
     bool fast = false;
     bool staged = false;
 };
@@ -156,6 +157,8 @@ struct mcd_catalog {
     double last_kernel_ms = -1.0, last_device_ms = -1.0;
     bool timing_pending = false;
     int64_t last_grid = 0, last_chunks = 0;
+    uint64_t launch_seq = 0;           // source of launch tags
+    int64_t n_reruns = 0;              // batches re-evaluated with the plain kernels (denormal regime of the reference)
 };
 
 namespace {
@@ -250,9 +253,11 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
         if ((e = hipMalloc(&w.d_params, (size_t)n_out * cat->k * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_wpar, (size_t)n_out * mcd::KD * term_bytes)) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_partials, std::max<size_t>(1, (size_t)n_walkers * w.n_chunks) * sizeof(double))) != hipSuccess) return e;
-        if ((e = hipMalloc(&w.d_out, (size_t)n_out * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&w.d_out, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;   // + re-run flag word
+        if ((e = hipMemset(w.d_out, 0, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
         if ((e = hipHostMalloc(&w.h_params, (size_t)n_out * cat->k * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
-        if ((e = hipHostMalloc(&w.h_out, (size_t)n_out * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
+        if ((e = hipHostMalloc(&w.h_out, (size_t)(n_out + 1) * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
+        std::memset(w.h_out, 0, (size_t)(n_out + 1) * sizeof(double));
         if ((e = hipHostGetDevicePointer((void**)&w.m_params, w.h_params, 0)) != hipSuccess) return e;
         if ((e = hipHostGetDevicePointer((void**)&w.m_out, w.h_out, 0)) != hipSuccess) return e;
         if (!chunks.empty() &&
@@ -325,6 +330,18 @@ int enqueue(mcd_catalog* cat) {
         const DeviceSlot& slot = ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast, w.uniform_len, sh.n};
+        // Re-run flag word behind the outputs.  One device: a fresh tag per launch, no reset needed.  Several ranks /
+        // devices: the word is zeroed, kernels write 1, and the word rides along in the all-reduce (count n_out + 1),
+        // so that every rank sees the same sum and takes the same decision.
+        const bool coll = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
+        shape.rerun_flag = (w.mapped ? w.m_out : w.d_out) + n_out;
+        if (coll) {
+            w.launch_tag = 1.0;
+            MCD_HIP(hipMemsetAsync(shape.rerun_flag, 0, sizeof(double), slot.stream));
+        } else {
+            w.launch_tag = (double)(++cat->launch_seq);
+        }
+        shape.launch_tag = w.launch_tag;
         hipEvent_t k0 = sh.ev_k0, k1 = sh.ev_k1;
         if (cat->timing_all) {
             if (sh.ring_used >= (size_t)1 << 16) sh.ring_used = 0;        // harness option left on: recycle, never grow without bound
@@ -357,7 +374,7 @@ int enqueue(mcd_catalog* cat) {
             WorkSet& w = sh.work.at(W);
             const DeviceSlot& slot = ctx->slots[sh.slot];
             MCD_HIP(hipSetDevice(slot.device));
-            MCD_NCCL(g_rccl.AllReduce(w.d_out, w.d_out, (size_t)n_out, ncclDouble, ncclSum, slot.comm, slot.stream));
+            MCD_NCCL(g_rccl.AllReduce(w.d_out, w.d_out, (size_t)n_out + 1, ncclDouble, ncclSum, slot.comm, slot.stream));
         }
         if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
     }
@@ -402,20 +419,57 @@ int sync_all(mcd_catalog* cat) {
     return MCD_OK;
 }
 
+int fetch_once(mcd_catalog* cat, bool* rerun) {
+    const int64_t W = cat->cur_walkers;
+    const int64_t n_out = cat->n_psets * W;
+    *rerun = false;
+    // every shard keeps its own flag word behind its outputs (all-reduced together with them in collective mode)
+    for (Shard& sh : cat->shards) {
+        WorkSet& w = sh.work.at(W);
+        const DeviceSlot& slot = cat->ctx->slots[sh.slot];
+        MCD_HIP(hipSetDevice(slot.device));
+        if (!w.mapped) {
+            const bool first = &sh == &cat->shards[0];
+            double* dst = first ? w.h_out : w.h_out + n_out;
+            const double* src = first ? w.d_out : w.d_out + n_out;
+            MCD_HIP(hipMemcpyAsync(dst, src, (size_t)(first ? n_out + 1 : 1) * sizeof(double), hipMemcpyDeviceToHost,
+                                   slot.stream));
+        }
+    }
+    int rc = sync_all(cat);
+    if (rc != MCD_OK) return rc;
+    const bool coll = cat->ctx->n_ranks > 1 || cat->ctx->slots.size() > 1 || cat->ctx->force_collective;
+    for (Shard& sh : cat->shards) {
+        WorkSet& w = sh.work.at(W);
+        if (!w.fast) continue;
+        const double flag = w.h_out[n_out];
+        if (coll ? flag > 0.0 : flag == w.launch_tag) *rerun = true;
+    }
+    return MCD_OK;
+}
+
 int fetch(mcd_catalog* cat, double* out) {
     if (!cat || !out) return fail(MCD_ERR_INVALID, "null catalogue or output");
     if (cat->cur_walkers <= 0) return fail(MCD_ERR_INVALID, "nothing evaluated yet");
     const int64_t W = cat->cur_walkers;
     const int64_t n_out = cat->n_psets * W;
-    Shard& sh = cat->shards[0];
-    WorkSet& w = sh.work.at(W);
-    const DeviceSlot& slot = cat->ctx->slots[sh.slot];
-    MCD_HIP(hipSetDevice(slot.device));
-    if (!w.mapped)
-        MCD_HIP(hipMemcpyAsync(w.h_out, w.d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
-    int rc = sync_all(cat);
+    bool rerun = false;
+    int rc = fetch_once(cat, &rerun);
     if (rc != MCD_OK) return rc;
-    std::memcpy(out, w.h_out, (size_t)n_out * sizeof(double));
+    if (rerun) {
+        // A fast mixture kernel met the regime where the reference's log-sum-exp runs on denormal numbers (a star with
+        // pmember == 1, f_back == 0 or density == 0 that is a > 37 sigma outlier of the remaining component).  Only the
+        // plain kernels reproduce the reference's value there: evaluate the staged batch again with them.  In a
+        // multi-rank job every rank must take the same decision (the all-reduce is collective): ranks agree through
+        // the all-reduced flag below.
+        ++cat->n_reruns;
+        for (Shard& sh : cat->shards) sh.work.at(W).fast = false;
+        rc = enqueue(cat);
+        if (rc != MCD_OK) return rc;
+        rc = fetch_once(cat, &rerun);
+        if (rc != MCD_OK) return rc;
+    }
+    std::memcpy(out, cat->shards[0].work.at(W).h_out, (size_t)n_out * sizeof(double));
     return MCD_OK;
 }
 
@@ -755,6 +809,8 @@ int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_lau
     for (Shard& s2 : cat->shards) s2.ring_used = 0;
     return MCD_OK;
 }
+
+int64_t mcd_rerun_count(const mcd_catalog* cat) { return cat ? cat->n_reruns : MCD_ERR_INVALID; }
 
 double mcd_last_kernel_ms(const mcd_catalog* cat) { return cat ? cat->last_kernel_ms : -1.0; }
 double mcd_last_device_ms(const mcd_catalog* cat) { return cat ? cat->last_device_ms : -1.0; }

@@ -22,6 +22,8 @@ struct LaunchShape {
     bool fast;        // product/fraction-tree path allowed (range guard passed)
     int uniform_len = 0;     // > 0: chunk c covers records [c * len, min((c + 1) * len, n_records)) of parameter set 0
     int64_t n_records = 0;
+    double* rerun_flag = nullptr;   // device word the fast mixture kernels set to `launch_tag` in the denormal regime
+    double launch_tag = 0.0;
 };
 
 // raw per-star columns on the device (float64), consumed once by prepare_records

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
                                                           const T* __restrict__ wpar,
                                                           double* __restrict__ partials, int64_t n_tasks,
                                                           int n_wtiles, int64_t n_walkers, int64_t n_chunks,
-                                                          int uniform_len, int64_t n_records) {
+                                                          int uniform_len, int64_t n_records,
+                                                          double* __restrict__ rerun_flag, double launch_tag) {
     constexpr int ND = record_doubles(MODEL, FREE);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kWave - 1);
@@ -164,7 +165,10 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
     w.load(wp);                                   // unused constants are dead code for a given MODEL
 
     // wave-uniform record pointer: the reads inside chunk_loglike become scalar loads
-    const double result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w);
+    bool denormal;
+    const double result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w, denormal);
+    // denormal regime of the reference's log-sum-exp met: tell the host to re-evaluate this batch with the plain kernels
+    if (FAST && denormal && active) *rerun_flag = launch_tag;
     if (active) partials[w_raw * n_chunks + chunk_id] = result;
 }
 
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(kBlock) void per_star_kernel(const T* __restrict__ 
 
 template <int MODEL, bool FREE, class T, class A, bool FAST>
 hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, int64_t n_chunks, const void* wpar,
-                      double* partials, int64_t n_walkers, int uniform_len, int64_t n_records) {
+                      double* partials, int64_t n_walkers, int uniform_len, int64_t n_records, double* rerun_flag,
+                      double launch_tag) {
     const int n_wtiles = (int)((n_walkers + kWave - 1) / kWave);
     const int64_t n_tasks = n_chunks * n_wtiles;
     int64_t grid = (n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -245,7 +250,7 @@ hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, i
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST>), dim3((unsigned)grid), dim3(kBlock), 0, s,
                        (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,
-                       uniform_len, n_records);
+                       uniform_len, n_records, rerun_flag, launch_tag);
     return hipGetLastError();
 }
 
@@ -254,22 +259,24 @@ hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* re
                             int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers) {
     const int uniform_len = sh.uniform_len;
     const int64_t n_records = sh.n_records;
+    double* const rerun_flag = sh.rerun_flag;
+    const double launch_tag = sh.launch_tag;
     switch (sh.precision) {
         case 0:
             if (sh.fast)
                 return launch_one<MODEL, FREE, double, double, true>(s, records, chunks, n_chunks, wpar, partials,
-                                                                     n_walkers, uniform_len, n_records);
-            return launch_one<MODEL, FREE, double, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records);
+                                                                     n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+            return launch_one<MODEL, FREE, double, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
         case 1:
             if (sh.fast && bg_kind(MODEL) == BG_NONE)
                 return launch_one<MODEL, FREE, float, float, bg_kind(MODEL) == BG_NONE>(s, records, chunks, n_chunks, wpar,
-                                                                                       partials, n_walkers, uniform_len, n_records);
-            return launch_one<MODEL, FREE, float, float, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records);
+                                                                                       partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+            return launch_one<MODEL, FREE, float, float, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
         case 2:
             if (sh.fast && bg_kind(MODEL) == BG_NONE)
                 return launch_one<MODEL, FREE, float, double, bg_kind(MODEL) == BG_NONE>(s, records, chunks, n_chunks, wpar,
-                                                                                        partials, n_walkers, uniform_len, n_records);
-            return launch_one<MODEL, FREE, float, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records);
+                                                                                        partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+            return launch_one<MODEL, FREE, float, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
     }
     return hipErrorInvalidValue;
 }

@@ -369,6 +369,13 @@ MCD_HD double exp_split(double u, int& k_out) {
     return p;
 }
 
+// x == +-0 tested on the bit pattern: for a wave-uniform x (SGPR pair) this stays on the scalar unit.
+MCD_HD bool is_zero_bits(double x) {
+    uint64_t b;
+    __builtin_memcpy(&b, &x, sizeof b);
+    return (b << 1) == 0;
+}
+
 MCD_HD double ldexp_(double x, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_ldexp(x, k);
@@ -390,7 +397,13 @@ MCD_HD double fmax_(double a, double b) {
 struct BgFixedAcc {
     LogProduct l;          // sum log y_i   (sum b_i is walker-independent: added once per parameter set by the reduce kernel)
     LogProduct lden;       // BG_FIXED_DENSITY: sum log(rho_i + f)
-    MCD_HD void init() { l.init(); lden.init(); }
+    int kmin;              // most negative exponent of a term whose other component is EXACTLY zero (see denormal())
+    MCD_HD void init() { l.init(); lden.init(); kmin = 0; }
+    // True when a star with pmember == 1 (or f_back == 0) had its cluster term below 2^-1000: there the reference's
+    // log-sum-exp (runner.py:282-284) works on DENORMAL numbers and its result carries their rounding noise
+    // (1e-7 .. 1e-2 absolute).  The library then re-evaluates the batch with the plain kernels, which execute the
+    // reference's expression literally, so that fast and plain results never differ by more than rounding.
+    MCD_HD bool denormal() const { return kmin < -1000; }
     MCD_HD void add_density(double d, double n, double rho, double f, double nbp) {
         add<false>(d, n, rho, f, nbp);           // f_back is a per-walker (VGPR) value here
         lden.mul(rho + f);
@@ -412,6 +425,12 @@ struct BgFixedAcc {
         const double y = UNIFORM_OMP ? fma_sgpr_addend(p * g, ldexp_(er, kc), omp) : fma_(p * g, ldexp_(er, kc), omp);
         l.mul_any(y);
         l.e32 += k - kc;
+        if constexpr (UNIFORM_OMP) {
+            if (is_zero_bits(omp)) kmin = k < kmin ? k : kmin;           // wave-uniform test: a scalar branch
+        } else {
+            const int kk = (omp == 0.0) ? k : 0;
+            kmin = kk < kmin ? kk : kmin;
+        }
     }
     MCD_HD void rescale() { l.rescale(); }
     MCD_HD void rescale_density() { l.rescale(); lden.rescale(); }
@@ -428,7 +447,9 @@ struct BgGaussAcc {
     double sum_min;        // sum min(w, wb)
     LogProduct ly;         // sum log y_i
     LogProduct lden;       // sum log(rho_i + f)
-    MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); }
+    int kmin;              // as BgFixedAcc::kmin: damped component below 2^-1000 while the other one is exactly zero
+    MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); kmin = 0; }
+    MCD_HD bool denormal() const { return kmin < -1000; }
     MCD_HD void add(double d, double n, double db, double nb, double rho, double f) {
         const double g = rsqrt_nr(n), gb = rsqrt_nr(nb);
         const double dg = d * g, dbg = db * gb;
@@ -445,6 +466,9 @@ struct BgGaussAcc {
         ly.mul_any(y);
         lden.mul(rho + f);
         sum_min += cluster_big ? w : wb;
+        const bool big_is_zero = cluster_big ? is_zero_bits(rho) : (f == 0.0);   // rho is wave-uniform, f loop-invariant
+        const int kk = big_is_zero ? k : 0;
+        kmin = kk < kmin ? kk : kmin;
     }
     MCD_HD void rescale() { ly.rescale(); lden.rescale(); }
     MCD_HD double finish(int64_t count) {
@@ -509,9 +533,11 @@ MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T&
     }
 }
 
+// `denormal` is set when a fast mixture path met the denormal regime described at BgFixedAcc::denormal().
 template <int MODEL, bool FREE, class T, class A, bool FAST>
-MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w) {
+MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w, bool& denormal) {
     constexpr int ND = record_doubles(MODEL, FREE);
+    denormal = false;
     constexpr int XB = geometry_doubles(MODEL, FREE);      // first background slot of a record
     constexpr int BG = bg_kind(MODEL);
     double result;
@@ -605,6 +631,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             acc.rescale();
         }
         result = acc.finish();
+        denormal = acc.denormal();
     } else if constexpr (BG == BG_FIXED_DENSITY && FAST) {
         BgFixedAcc acc;
         acc.init();
@@ -626,6 +653,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             acc.rescale_density();
         }
         result = acc.finish_density();
+        denormal = acc.denormal();
     } else if constexpr (BG == BG_GAUSS && FAST) {
         BgGaussAcc acc;
         acc.init();
@@ -647,6 +675,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             acc.rescale();
         }
         result = acc.finish(count);
+        denormal = acc.denormal();
     } else {
         A sum = 0;
 #pragma unroll 2

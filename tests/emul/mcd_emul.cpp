@@ -16,9 +16,22 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
         WalkerConsts<double> c;
         c.load(wpar + w * KD);
         double total = 0.0;
+        bool rerun = false;
         for (int64_t s = 0; s < n; s += chunk_len) {
             const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
-            total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c);
+            bool denormal;
+            total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c, denormal);
+            rerun = rerun || denormal;
+        }
+        if (FAST && rerun) {                          // what the library does: the batch is re-evaluated with the plain kernels
+            total = 0.0;
+            for (int64_t s = 0; s < n; s += chunk_len) {
+                const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
+                bool dummy;
+                total += chunk_loglike<MODEL, FREE, double, double, false>(recs + s * ND, count, c, dummy);
+            }
+            out[w] = total;
+            continue;
         }
         if (FAST && (bg_kind(MODEL) == BG_FIXED || bg_kind(MODEL) == BG_FIXED_DENSITY)) {
             // walker-independent sum of lnL_bg: added by the reduce kernel on the GPU

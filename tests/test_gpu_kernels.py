@@ -360,6 +360,7 @@ def test_fast_and_plain_kernels_agree_over_wide_ranges(native, ctx, model):
     which walkers are -inf.  This exercises v_rsq_f64 / v_rcp_f64 + Newton steps on the hardware."""
     from test_guard_random_cpu import CENTRE, MODELS, random_case
     rng = np.random.default_rng(500 + model)
+    reruns = 0
     for trial in range(25):
         cat, params = random_case(rng, model, n=500, w=70)
         kw = {}
@@ -372,9 +373,11 @@ def test_fast_and_plain_kernels_agree_over_wide_ranges(native, ctx, model):
         g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model, centre=CENTRE, **kw)
         assert g.k == MODELS[model]
         fast = g.loglike(params)
+        reruns += g.rerun_count
         g.set_option("fast_path", 0)
         plain = g.loglike(params)
         g.close()
         assert np.array_equal(np.isfinite(fast), np.isfinite(plain)), (trial, fast, plain)
         ok = np.isfinite(plain)
         assert rel_err(fast[ok], plain[ok]) < 1e-11, trial
+    assert reruns == 0 or model in (1, 2, 4, 5)          # only mixtures can meet the reference's denormal regime

@@ -43,7 +43,7 @@ def test_guarded_fast_path_agrees_with_plain_path(model):
     rng = np.random.default_rng(100 + model)
     admitted = refused = 0
     for trial in range(60):
-        cat, params = random_case(rng, model)
+        cat, params = random_case(rng, model, n=300 if trial % 2 else 500, w=6 if trial % 2 else 70)
         assert params.shape[1] == MODELS[model]
         plain = emul.loglike(cat, params, model, CENTRE, 0, chunk_len=64)
         if not emul.fast_guard(cat, params, model, CENTRE):
@@ -54,7 +54,7 @@ def test_guarded_fast_path_agrees_with_plain_path(model):
         both = np.isfinite(plain) & np.isfinite(fast)
         assert np.array_equal(np.isfinite(plain), np.isfinite(fast)), (trial, plain, fast)
         assert rel_err(fast[both], plain[both]) < 1e-11, (trial, plain, fast)
-    assert admitted >= 30, (admitted, refused)            # the guard must not be so strict that it is never used
+    assert admitted >= 20, (admitted, refused)            # the guard must not be so strict that it is never used
 
 
 def test_guard_refuses_what_the_fast_paths_cannot_represent():
