@@ -175,6 +175,19 @@ struct LogProduct {
         p *= m;
         e32 += ex;
     }
+    // as mul_any, additionally keeping the smallest binary exponent seen (one v_min_i32): a factor below 2^-1000
+    // marks the denormal regime of the reference's log-sum-exp (see BgFixedAcc::denormal)
+    MCD_HD void mul_any_track(double x, int& emin) {
+        int ex;
+#if defined(__HIP_DEVICE_COMPILE__)
+        double m = __builtin_frexp(x, &ex);
+#else
+        double m = std::frexp(x, &ex);
+#endif
+        p *= m;
+        e32 += ex;
+        emin = ex < emin ? ex : emin;
+    }
     MCD_HD double value() {
         rescale();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -397,13 +410,15 @@ MCD_HD double fmax_(double a, double b) {
 struct BgFixedAcc {
     LogProduct l;          // sum log y_i   (sum b_i is walker-independent: added once per parameter set by the reduce kernel)
     LogProduct lden;       // BG_FIXED_DENSITY: sum log(rho_i + f)
-    int kmin;              // most negative exponent of a term whose other component is EXACTLY zero (see denormal())
-    MCD_HD void init() { l.init(); lden.init(); kmin = 0; }
-    // True when a star with pmember == 1 (or f_back == 0) had its cluster term below 2^-1000: there the reference's
+    int emin;              // smallest binary exponent of any mixture value y_i (see denormal())
+    MCD_HD void init() { l.init(); lden.init(); emin = 0; }
+    // True when some y_i fell below 2^-1000.  Since 1 - p >= 2^-53 unless p == 1 exactly, that only happens for a star
+    // with pmember == 1 (or a walker with f_back == 0) whose cluster term is e^-693 or less: there the reference's
     // log-sum-exp (runner.py:282-284) works on DENORMAL numbers and its result carries their rounding noise
     // (1e-7 .. 1e-2 absolute).  The library then re-evaluates the batch with the plain kernels, which execute the
     // reference's expression literally, so that fast and plain results never differ by more than rounding.
-    MCD_HD bool denormal() const { return kmin < -1000; }
+    // (y_i == 0 exactly gives -inf on both paths and needs no re-run.)
+    MCD_HD bool denormal() const { return emin < -1000; }
     MCD_HD void add_density(double d, double n, double rho, double f, double nbp) {
         add<false>(d, n, rho, f, nbp);           // f_back is a per-walker (VGPR) value here
         lden.mul(rho + f);
@@ -423,14 +438,8 @@ struct BgFixedAcc {
         // the reference returns there (runner.py:283: log(1 * exp(m - b) + 0) with exp underflowing).
         const int kc = k > 1000 ? 1000 : k;
         const double y = UNIFORM_OMP ? fma_sgpr_addend(p * g, ldexp_(er, kc), omp) : fma_(p * g, ldexp_(er, kc), omp);
-        l.mul_any(y);
+        l.mul_any_track(y, emin);
         l.e32 += k - kc;
-        if constexpr (UNIFORM_OMP) {
-            if (is_zero_bits(omp)) kmin = k < kmin ? k : kmin;           // wave-uniform test: a scalar branch
-        } else {
-            const int kk = (omp == 0.0) ? k : 0;
-            kmin = kk < kmin ? kk : kmin;
-        }
     }
     MCD_HD void rescale() { l.rescale(); }
     MCD_HD void rescale_density() { l.rescale(); lden.rescale(); }
@@ -447,9 +456,9 @@ struct BgGaussAcc {
     double sum_min;        // sum min(w, wb)
     LogProduct ly;         // sum log y_i
     LogProduct lden;       // sum log(rho_i + f)
-    int kmin;              // as BgFixedAcc::kmin: damped component below 2^-1000 while the other one is exactly zero
-    MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); kmin = 0; }
-    MCD_HD bool denormal() const { return kmin < -1000; }
+    int emin;              // as BgFixedAcc::emin: y_i < 2^-1000 needs the undamped component to be exactly zero
+    MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); emin = 0; }
+    MCD_HD bool denormal() const { return emin < -1000; }
     MCD_HD void add(double d, double n, double db, double nb, double rho, double f) {
         const double g = rsqrt_nr(n), gb = rsqrt_nr(nb);
         const double dg = d * g, dbg = db * gb;
@@ -463,12 +472,9 @@ struct BgGaussAcc {
         // if the undamped component is exactly zero (f_back = 0 or density = 0) and e^{-delta} underflows, y = 0 and
         // lnL = -inf -- the same as the reference's log-sum-exp about the larger exponent (constant.py:320-323).
         const double y = cluster_big ? fma_(b, e, a) : fma_(a, e, b);
-        ly.mul_any(y);
+        ly.mul_any_track(y, emin);
         lden.mul(rho + f);
         sum_min += cluster_big ? w : wb;
-        const bool big_is_zero = cluster_big ? is_zero_bits(rho) : (f == 0.0);   // rho is wave-uniform, f loop-invariant
-        const int kk = big_is_zero ? k : 0;
-        kmin = kk < kmin ? kk : kmin;
     }
     MCD_HD void rescale() { ly.rescale(); lden.rescale(); }
     MCD_HD double finish(int64_t count) {

@@ -23,7 +23,7 @@ KERNELS = [  # (template tag, name, stars per loop iteration)
     ("ILi0ELb0EddLb1E", "CONST fixed centre", 8), ("ILi0ELb1EddLb1E", "CONST free centre", 8),
     ("ILi1ELb0EddLb1E", "BGFIXED fixed centre", 4), ("ILi2ELb0EddLb1E", "BGGAUSS fixed centre", 4),
     ("ILi3ELb0EddLb1E", "PROFILE fixed centre", 8), ("ILi4ELb0EddLb1E", "PROFILE_BGGAUSS fixed", 4),
-    ("ILi5ELb0EddLb1E", "PROFILE_BGDENS fixed", 4), ("ILi0ELb0EffLb1E", "CONST fixed, f32", 4),
+    ("ILi5ELb0EddLb1E", "PROFILE_BGDENS fixed", 4), ("ILi0ELb0EffLb1E", "CONST fixed, f32", 16),
 ]
 
 
@@ -41,16 +41,17 @@ def main():
         if not starts:
             continue
         a = starts[0]
-        e = next(i for i in range(a, len(asm)) if "s_endpgm" in asm[i])
+        e = next(i for i in range(a, len(asm)) if asm[i].startswith(".Lfunc_end"))   # kernels may have several s_endpgm
         k = asm[a:e]
         labels = {l.split(":")[0]: i for i, l in enumerate(k) if re.match(r"^\.LBB\d+_\d+:", l)}
-        best = None
+        spans = []
         for i, l in enumerate(k):
             m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
             if m and m.group(1) in labels and labels[m.group(1)] < i:
-                span = (labels[m.group(1)], i)
-                if best is None or span[1] - span[0] > best[1] - best[0]:
-                    best = span
+                spans.append((labels[m.group(1)], i))
+        # innermost loops only (no other loop nested inside); the hot loop is the largest of them
+        inner = [sp for sp in spans if not any(o != sp and sp[0] <= o[0] and o[1] <= sp[1] for o in spans)]
+        best = max(inner, key=lambda sp: sp[1] - sp[0])
         body = [l.split()[0] for l in k[best[0]:best[1]] if l.startswith("\t") and not l.strip().startswith((";", "."))]
         c = Counter(body)
         f64 = sum(v for o, v in c.items() if o.startswith("v_") and "f64" in o)
