@@ -381,3 +381,30 @@ def test_fast_and_plain_kernels_agree_over_wide_ranges(native, ctx, model):
         ok = np.isfinite(plain)
         assert rel_err(fast[ok], plain[ok]) < 1e-11, trial
     assert reruns == 0 or model in (1, 2, 4, 5)          # only mixtures can meet the reference's denormal regime
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 5])
+def test_fast_and_plain_kernels_agree_free_centre(native, ctx, model):
+    """Same as above with the centre as a walker parameter (geometry recomputed per term)."""
+    from test_guard_random_cpu import CENTRE, random_case
+    rng = np.random.default_rng(900 + model)
+    head = 6 if model >= 3 else 4
+    for trial in range(8):
+        cat, params = random_case(rng, model, n=400, w=66)
+        centre_cols = np.column_stack([CENTRE[0] + rng.normal(0, 0.01, len(params)), CENTRE[1] + rng.normal(0, 0.01, len(params))])
+        params = np.hstack([params[:, :head], centre_cols, params[:, head:]])
+        kw = {}
+        if model == 1:
+            kw = dict(lnlike_bg=cat["lnlike_bg"], pmember=cat["pmember"])
+        elif model == 2:
+            kw = dict(density=cat["density"])
+        elif model == 5:
+            kw = dict(lnlike_bg=cat["lnlike_bg"], density=cat["density"])
+        g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model, centre=None, **kw)
+        fast = g.loglike(params)
+        g.set_option("fast_path", 0)
+        plain = g.loglike(params)
+        g.close()
+        assert np.array_equal(np.isfinite(fast), np.isfinite(plain)), trial
+        ok = np.isfinite(plain)
+        assert rel_err(fast[ok], plain[ok]) < 1e-11, trial
