@@ -248,3 +248,54 @@ def test_stretch_move_samples_a_gaussian():
         EnsembleSampler(4, 3, log_prob)
     with pytest.raises(ValueError, match="NaN"):
         EnsembleSampler(8, 2, lambda x: np.full(len(x), np.nan), vectorize=True).run_mcmc(np.zeros((8, 2)), 1)
+
+
+def test_batch_plan_matches_the_per_parameter_path():
+    """The cached batch plan of lnprob_batch (flat bounds check + kernel table by index) against the generic
+    resolve_batch / lnprior_batch / _kernel_table path, with a stand-in catalogue that echoes its table."""
+    from mcmc_dynamics_amd.analysis import ModelFitGB
+
+    class Echo(object):
+        def __init__(self):
+            self.tables = []
+
+        def loglike(self, table):
+            self.tables.append(np.array(table))
+            return table.sum(axis=1)
+
+    reader, c = small_reader()
+    rng = np.random.default_rng(4)
+    for cls, fix in ((ConstantFit, True), (ConstantFitGB, False), (ModelFitGB, True)):
+        obj = cls(reader)
+        if fix:
+            obj.parameters["ra_center"].set(value=56.345, fixed=True)
+            obj.parameters["dec_center"].set(value=-26.675, fixed=True)
+        else:
+            obj.parameters["ra_center"].set(value=56.345)
+            obj.parameters["dec_center"].set(value=-26.675)
+        if cls is ModelFitGB:
+            obj.parameters["a"].set(unit="arcmin")            # a unit conversion in the kernel table (arcmin -> arcsec)
+        names = obj.fitted_parameters
+        vals = rng.normal(1.0, 2.0, size=(40, len(names)))
+        for j, n in enumerate(names):
+            if n == "ra_center":
+                vals[:, j] = 56.345 + 0.01 * rng.normal(size=40)
+            if n == "dec_center":
+                vals[:, j] = -26.675 + 0.01 * rng.normal(size=40)
+        vals[3, names.index("sigma_max")] = -0.5              # rejected rows
+        vals[7, 0] = np.nan
+        echo = Echo()
+        obj._catalog, obj._catalog_key = echo, obj._catalog_spec()[0]
+        obj._ensure_catalog = lambda echo=echo: echo
+        fast = obj.lnprob_batch(vals)
+        resolved = obj.parameters.resolve_batch(vals)
+        lp = obj.parameters.lnprior_batch(resolved)
+        ok = np.isfinite(lp)
+        assert np.array_equal(np.isfinite(fast), ok) and not ok[3] and not ok[7]
+        slow_table = obj._kernel_table(resolved)
+        assert np.allclose(fast[ok], slow_table[ok].sum(axis=1) + lp[ok], rtol=1e-14, atol=0)
+        assert echo.tables[0].shape == slow_table.shape and np.array_equal(echo.tables[0][ok], slow_table[ok])
+        # changing a bound or fixing a parameter invalidates the plan
+        obj.parameters["v_sys"].set(max=0.0)
+        again = obj.lnprob_batch(vals)
+        assert np.array_equal(np.isfinite(again), ok & (vals[:, 0] <= 0.0))
