@@ -408,3 +408,43 @@ def test_fast_and_plain_kernels_agree_free_centre(native, ctx, model):
         assert np.array_equal(np.isfinite(fast), np.isfinite(plain)), trial
         ok = np.isfinite(plain)
         assert rel_err(fast[ok], plain[ok]) < 1e-11, trial
+
+
+@pytest.mark.parametrize("model", [1, 2, 5])
+def test_binned_mixture_models(native, ctx, model):
+    """Radial bins with the mixture likelihoods: every bin's value equals a stand-alone catalogue of that bin's
+    stars (per-bin constants such as the hoisted sum of lnL_bg included), for per-bin walker ensembles."""
+    from mcmc_dynamics_amd import synthetic
+    from oracle import lnprob_numpy as oracle
+    from test_guard_random_cpu import random_case, CENTRE
+    rng = np.random.default_rng(40 + model)
+    cat, params = random_case(rng, model, n=6000, w=40)
+    dx, dy = oracle.calc_xy_offset(cat["ra"], cat["dec"], *CENTRE)
+    bins = oracle.make_radial_bins(np.hypot(dx, dy), 700, 0.05).astype(np.int64)
+    order = np.argsort(bins, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(bins))])
+    n_bins = len(offs) - 1
+    assert n_bins >= 4
+    srt = {k: v[order] for k, v in cat.items()}
+
+    def kw(sl):
+        if model == 1:
+            return dict(lnlike_bg=srt["lnlike_bg"][sl], pmember=srt["pmember"][sl])
+        if model == 2:
+            return dict(density=srt["density"][sl])
+        return dict(lnlike_bg=srt["lnlike_bg"][sl], density=srt["density"][sl])
+
+    per_bin_params = np.stack([params * (1.0 + 0.002 * b) for b in range(n_bins)])
+    if model in (2, 5):
+        per_bin_params[..., -1] = np.clip(per_bin_params[..., -1], 0.0, 1.0)
+    full = native.Catalog(ctx, srt["ra"], srt["dec"], srt["v"], srt["verr"], model=model, centre=CENTRE,
+                          bin_offsets=offs, **kw(slice(None)))
+    got = full.loglike(per_bin_params)
+    assert got.shape == (n_bins, 40)
+    for b in range(n_bins):
+        sl = slice(offs[b], offs[b + 1])
+        one = native.Catalog(ctx, srt["ra"][sl], srt["dec"][sl], srt["v"][sl], srt["verr"][sl], model=model,
+                             centre=CENTRE, **kw(sl))
+        want = one.loglike(per_bin_params[b])
+        one.close()
+        assert rel_err(got[b], want) < RTOL, b
