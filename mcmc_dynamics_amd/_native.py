@@ -153,6 +153,7 @@ class Context(object):
             _check(self.lib, rc, "mcd_ctx_create")
             self.rank, self.n_ranks = 0, 1
         self.handle = handle
+        self._catalogs = weakref.WeakSet()        # catalogues living on this context: closed before it
         _live_contexts.add(self)
 
     @staticmethod
@@ -168,6 +169,8 @@ class Context(object):
 
     def close(self):
         if getattr(self, "handle", None):
+            for cat in list(getattr(self, "_catalogs", ())):
+                cat.close()
             self.lib.mcd_ctx_destroy(self.handle)
             self.handle = None
 
@@ -230,6 +233,7 @@ class Catalog(object):
         self.k = self.lib.mcd_catalog_param_count(handle)
         self._walkers = 0
         _live_catalogs.add(self)
+        ctx._catalogs.add(self)
 
     def _params(self, params):
         p = _f64(params)
@@ -249,8 +253,13 @@ class Catalog(object):
             raise ValueError("params have {0} columns, catalogue expects {1}".format(p.shape[-1], self.k))
         return np.ascontiguousarray(p), w
 
+    def _alive(self):
+        if not getattr(self, "handle", None):
+            raise NativeError("catalogue is closed")
+
     def loglike(self, params):
         """(W, K) -> (W,)   [binned: (B, W, K) -> (B, W)]   synchronous."""
+        self._alive()
         p, w = self._params(params)
         out = np.empty((self.n_sets, w) if self.n_sets > 1 else (w,), dtype=np.float64)
         rc = self.lib.mcd_loglike_batch(self.handle, w, self.k, _ptr(p), _ptr(out))

@@ -448,3 +448,19 @@ def test_binned_mixture_models(native, ctx, model):
         want = one.loglike(per_bin_params[b])
         one.close()
         assert rel_err(got[b], want) < RTOL, b
+
+
+def test_lifetime_order_is_safe(native):
+    """Closing a context closes its catalogues first; a closed catalogue refuses work instead of crashing."""
+    from mcmc_dynamics_amd import synthetic
+    c, centre = _synthetic(500, 2)
+    pos = synthetic.make_walkers(8, NAMES4, c["truth"], config=2)
+    ctx2 = native.Context(n_devices=1)
+    cat = native.Catalog(ctx2, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
+    assert np.all(np.isfinite(cat.loglike(pos)))
+    ctx2.close()
+    assert cat.handle is None
+    with pytest.raises(native.NativeError):
+        cat.loglike(pos)
+    cat.close()
+    ctx2.close()
