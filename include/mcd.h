@@ -151,6 +151,16 @@ int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* ou
  * ModelFitConstantBackground (analysis/model.py:565-623); defined for every background model. */
 int mcd_loglike_per_star(mcd_catalog* cat, int32_t k, const double* params, double* out);
 
+/* Background log-likelihood of n test stars against the kernel-density estimate built from n_comp comparison
+ * stars: replaces background.SingleStars.__call__ (background/single_stars.py:42-77), the O(n * n_comp) precompute
+ * whose output is the `lnlike_bg` column of a MCD_MODEL_CONST_BGFIXED / _PROFILE_BGDENS catalogue (runner.py:96-106).
+ *   out_i = log( (1 / n_comp) sum_j N(v_i - comp_j; verr_i^2 + sigma_int^2) ),   all velocities in km/s.
+ * Runs on the first device of `ctx`; host buffers in, n doubles out; synchronous.  n = 0 is a no-op; n_comp = 0 is
+ * MCD_ERR_INVALID (the reference raises on the empty maximum). `kernel_ms`, if not NULL, receives the HIP-event time
+ * of the two kernels. */
+int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t n, const double* v,
+                       const double* verr, double sigma_int, double* out, double* kernel_ms);
+
 /* ---- introspection for the measurement harness ------------------------------------------- */
 
 const char* mcd_last_error(void);

@@ -43,6 +43,8 @@ SYMBOLS = {
     "mcd_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_membership": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_double_p, _c_double_p]),
     "mcd_loglike_per_star": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_double_p, _c_double_p]),
+    "mcd_kde_background": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int64, _c_double_p,
+                                          _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
     "mcd_last_error": (ctypes.c_char_p, []),
     "mcd_abi_version": (ctypes.c_int, []),
     "mcd_last_kernel_ms": (ctypes.c_double, [ctypes.c_void_p]),
@@ -166,6 +168,20 @@ class Context(object):
     @property
     def n_devices(self):
         return self.lib.mcd_ctx_n_devices(self.handle)
+
+    def kde_background(self, comp, v, verr, sigma_int=0.0, return_kernel_ms=False):
+        """``background.SingleStars.__call__`` (single_stars.py:42-77) for km/s arrays: (n,) log-likelihoods."""
+        if not getattr(self, "handle", None):
+            raise NativeError("context is closed")
+        comp, v, verr = _f64(comp).ravel(), _f64(v).ravel(), _f64(verr).ravel()
+        if v.shape != verr.shape:
+            raise ValueError("v and verr must have the same shape")
+        out = np.empty(v.size, dtype=np.float64)
+        ms = ctypes.c_double(0.0)
+        rc = self.lib.mcd_kde_background(self.handle, comp.size, _ptr(comp), v.size, _ptr(v), _ptr(verr),
+                                         float(sigma_int), _ptr(out), ctypes.byref(ms))
+        _check(self.lib, rc, "mcd_kde_background")
+        return (out, ms.value) if return_kernel_ms else out
 
     def close(self):
         if getattr(self, "handle", None):

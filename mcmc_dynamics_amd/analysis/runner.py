@@ -136,7 +136,11 @@ class Runner(object):
                 "'background' must be an instance of a Background class."
             if "pmember" not in self.data.data.columns:
                 logger.error("Inclusion of background population requires prior probabilities for membership.")
-            self.lnlike_background = np.asarray(self.background(self.v, self.verr), dtype=np.float64)
+            if isinstance(background, SingleStars):        # O(N M) kernel-density precompute: on the device
+                lnbg = self.background(self.v, self.verr, context=context)
+            else:
+                lnbg = self.background(self.v, self.verr)
+            self.lnlike_background = np.asarray(lnbg, dtype=np.float64)
             self.pmember = data.column("pmember")
         else:
             self.lnlike_background = None

@@ -763,6 +763,59 @@ int mcd_loglike_per_star(mcd_catalog* cat, int32_t k, const double* params, doub
     return per_star(cat, k, params, 1, out);
 }
 
+namespace {
+// device scratch of mcd_kde_background, released on every exit path
+struct KdeScratch {
+    double *comp = nullptr, *v = nullptr, *verr = nullptr, *dmin = nullptr, *sum = nullptr, *out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~KdeScratch() {
+        for (double* p : {comp, v, verr, dmin, sum, out})
+            if (p) (void)hipFree(p);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+}  // namespace
+
+int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t n, const double* v,
+                       const double* verr, double sigma_int, double* out, double* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (!ctx || ctx->slots.empty()) return fail(MCD_ERR_INVALID, "kde background: null context");
+    if (n < 0 || n_comp < 0) return fail(MCD_ERR_INVALID, "kde background: negative size");
+    if (n == 0) return MCD_OK;
+    if (n_comp == 0) return fail(MCD_ERR_INVALID, "kde background: no comparison stars");
+    if (!comp || !v || !verr || !out) return fail(MCD_ERR_INVALID, "kde background: null argument");
+    if (!(sigma_int == sigma_int)) return fail(MCD_ERR_INVALID, "kde background: sigma_int is NaN");
+    const DeviceSlot& slot = ctx->slots[0];
+    MCD_HIP(hipSetDevice(slot.device));
+    int slice_len = 0;
+    const int n_slices = mcd::kde_slices(n, n_comp, &slice_len);
+    KdeScratch d;
+    MCD_HIP(hipMalloc(&d.comp, (size_t)n_comp * sizeof(double)));
+    MCD_HIP(hipMalloc(&d.v, (size_t)n * sizeof(double)));
+    MCD_HIP(hipMalloc(&d.verr, (size_t)n * sizeof(double)));
+    MCD_HIP(hipMalloc(&d.dmin, (size_t)n * n_slices * sizeof(double)));
+    MCD_HIP(hipMalloc(&d.sum, (size_t)n * n_slices * sizeof(double)));
+    MCD_HIP(hipMalloc(&d.out, (size_t)n * sizeof(double)));
+    MCD_HIP(hipEventCreate(&d.e0));
+    MCD_HIP(hipEventCreate(&d.e1));
+    MCD_HIP(hipMemcpyAsync(d.comp, comp, (size_t)n_comp * sizeof(double), hipMemcpyHostToDevice, slot.stream));
+    MCD_HIP(hipMemcpyAsync(d.v, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, slot.stream));
+    MCD_HIP(hipMemcpyAsync(d.verr, verr, (size_t)n * sizeof(double), hipMemcpyHostToDevice, slot.stream));
+    MCD_HIP(hipEventRecord(d.e0, slot.stream));
+    MCD_HIP(mcd::launch_kde(slot.stream, d.comp, n_comp, d.v, d.verr, n, sigma_int, slice_len, n_slices, d.dmin, d.sum,
+                            d.out));
+    MCD_HIP(hipEventRecord(d.e1, slot.stream));
+    MCD_HIP(hipMemcpyAsync(out, d.out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
+    MCD_HIP(hipStreamSynchronize(slot.stream));
+    if (kernel_ms) {
+        float ms = 0.f;
+        MCD_HIP(hipEventElapsedTime(&ms, d.e0, d.e1));
+        *kernel_ms = ms;
+    }
+    return MCD_OK;
+}
+
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
     if (!cat || !key) return fail(MCD_ERR_INVALID, "mcd_set_option: null argument");
     if (!std::strcmp(key, "timing")) {

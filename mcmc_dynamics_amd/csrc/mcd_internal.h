@@ -58,4 +58,10 @@ hipError_t launch_per_star(hipStream_t s, const LaunchShape& shape, const void* 
 
 int record_bytes(int model, bool free_centre, int precision);
 
+// background.SingleStars (mcd_kde.hip): slice plan and launch.  part_dmin / part_sum hold [n_slices][n] doubles.
+int kde_slices(int64_t n, int64_t m, int* slice_len);
+hipError_t launch_kde(hipStream_t s, const double* comp, int64_t m, const double* v, const double* verr, int64_t n,
+                      double sigma_int, int slice_len, int n_slices, double* part_dmin, double* part_sum,
+                      double* out);
+
 }  // namespace mcd

@@ -483,6 +483,43 @@ struct BgGaussAcc {
 };
 
 // ---------------------------------------------------------------------------------------------
+// background.SingleStars (single_stars.py:42-77): one test star against a slice of the comparison stars.
+//   e_j = -(c_j - v)^2 h,  h = 1 / (2 (verr^2 + sigma_int^2));   slice result: nearest distance + sum_j exp(e_j - e_max)
+// Two passes over the slice: the nearest comparison star gives the largest exponent exactly, every term of the
+// second pass then has a non-positive exponent and the nearest star contributes exactly 1.
+MCD_HD double fmin_(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmin(a, b);              // v_min_f64
+#else
+    return std::fmin(a, b);
+#endif
+}
+MCD_HD double fabs_(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fabs(a);                 // source modifier, no instruction
+#else
+    return std::fabs(a);
+#endif
+}
+struct KdeLane {
+    double v, h, d2min, sum;
+    MCD_HD void init(double v_, double verr, double sigma_int2) {
+        v = v_;
+        h = 0.5 / fma_(verr, verr, sigma_int2);
+    }
+    MCD_HD void nearest(double c, double& dmin) const { dmin = fmin_(dmin, fabs_(c - v)); }
+    MCD_HD void begin_sum(double dmin) { d2min = dmin * dmin; sum = 0.0; }
+    MCD_HD void add(double c) {
+        const double d = c - v;
+        // exp(u) == 0 in f64 below u = -745.2; the clamp keeps k inside int range for far outliers
+        const double u = fmax_(fma_(-d, d, d2min) * h, -800.0);
+        int k;
+        const double er = exp_split(u, k);
+        sum += ldexp_(er, k);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // One chunk of stars for one walker.  On the GPU `r` is wave-uniform (lane = walker), so every record
 // read below is a scalar load and the record values are SGPR operands of the vector ops.
 template <class T> struct WalkerConsts {

@@ -60,6 +60,26 @@ def gaussian_background(v, verr, mean, sigma):
     return -0.5 * np.log(2. * np.pi * norm) + exponent
 
 
+def single_stars_background(comp, v, verr, sigma_int=0.0, block=20000):
+    """background/single_stars.py:42-77: log of the mean of M Gaussian kernels N(v_i - comp_j; verr_i^2 + sigma_int^2),
+    with the reference's log-sum-exp (largest exponent subtracted per test star).  Evaluated in column blocks so the
+    (M, N) outer product stays small; each column is computed exactly as in the reference."""
+    comp = np.asarray(comp, dtype=np.float64)
+    v = np.asarray(v, dtype=np.float64)
+    verr = np.asarray(verr, dtype=np.float64)
+    norm_all = sigma_int ** 2 + verr ** 2
+    out = np.empty(v.size, dtype=np.float64)
+    block = max(1, min(block, int(4_000_000 // max(1, comp.size))))
+    for s in range(0, v.size, block):
+        e = slice(s, s + block)
+        norm = norm_all[e]
+        exp_coeff = -(np.subtract.outer(comp, v[e])) ** 2 / (2. * norm)
+        exp_coeff_max = np.max(exp_coeff, axis=0)
+        out[e] = exp_coeff_max + np.log(np.sum(np.exp(exp_coeff - exp_coeff_max) / (np.sqrt(2. * np.pi * norm)),
+                                               axis=0)) - np.log(comp.size)
+    return out
+
+
 def calculate_lnlike(v, verr, v_los, sigma_los, lnlike_background=None, pmember=None):
     """analysis/runner.py:240-286."""
     norm = verr * verr + sigma_los * sigma_los                     # :261

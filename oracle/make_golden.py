@@ -30,7 +30,7 @@ from astropy import units as u          # noqa: E402
 
 from mcmc_dynamics.analysis import (ConstantFit, ConstantFitGB, ModelFit, ModelFitGB,   # noqa: E402
                                     ModelFitConstantBackground)
-from mcmc_dynamics.background import Gaussian                              # noqa: E402
+from mcmc_dynamics.background import Gaussian, SingleStars                 # noqa: E402
 from mcmc_dynamics.utils.files import DataReader                           # noqa: E402
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -95,8 +95,38 @@ def walkers_with_rejections(cat_truth, names, n, config):
     return pos
 
 
+def golden_single_stars():
+    """background.SingleStars (KDE over comparison stars, single_stars.py:42-77) and a ConstantFit that uses it."""
+    ra_c, dec_c = synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG
+    catb = synthetic.make_catalog(1200, config=3, background=True)
+    rng = np.random.default_rng(424242)
+    comp = np.concatenate([rng.normal(20.0, 40.0, 340), [250.0, -310.5]])        # two isolated comparison stars
+    v, verr = catb["v"].copy(), catb["verr"].copy()
+    v[3], verr[3] = 900.0, 0.05            # > 1e4 sigma from every comparison star: all but the nearest kernel underflow
+    v[4], verr[4] = comp[17], 0.3          # exactly on a comparison star (largest exponent = 0)
+    catb["v"], catb["verr"] = v, verr
+    ss = SingleStars(comp * KMS)
+    out = {}
+    for tag, s_int in (("s0", 0.0), ("s2", 2.5)):
+        res = ss(v * KMS, verr * KMS, sigma_int=s_int * KMS)
+        out["lnlike_" + tag] = np.asarray(getattr(res, "value", res), dtype=np.float64)
+    one = SingleStars(np.array([12.5]) * KMS)(v[:50] * KMS, verr[:50] * KMS)      # M = 1
+    cf = ConstantFit(reader(catb, extra=("pmember",)), background=ss)
+    fix_center(cf, ra_c, dec_c)
+    names = list(cf.fitted_parameters)
+    pos = walkers_with_rejections(catb["truth"], names, 12, config=3)
+    save("single_stars", comp=comp, ra=catb["ra"], dec=catb["dec"], v=v, verr=verr, pmember=catb["pmember"],
+         sigma_int_s0=0.0, sigma_int_s2=2.5, lnlike_m1=np.asarray(getattr(one, "value", one), dtype=np.float64),
+         lnlike_background=np.asarray(cf.lnlike_background, dtype=np.float64),
+         ra_center=ra_c, dec_center=dec_c, names=names, values=pos, lnprob=lnprobs(cf, pos), lnprior=lnpriors(cf, pos),
+         **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["single_stars"]:          # regenerate one fixture without rewriting the others
+        return golden_single_stars()
+    golden_single_stars()
     ra_c, dec_c = synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG
 
     # ---------------------------------------------------------------- ConstantFit, fixed centre

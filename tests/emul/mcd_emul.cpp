@@ -87,3 +87,33 @@ extern "C" int emul_fast_guard(int model, int free_centre, int f32, int64_t n, c
     const CatalogStats st = compute_stats(n, v, verr, lnbg, pmember, density, bg_kind(model));
     return fast_guard(st, model, free_centre != 0, f32 != 0, k, params, n_rows) ? 1 : 0;
 }
+
+// background.SingleStars: the device's per-lane slice arithmetic (KdeLane) and the slice combination of
+// csrc/mcd_kde.hip: kde_combine_kernel, on the CPU
+extern "C" int emul_kde(int64_t m, const double* comp, int64_t n, const double* v, const double* verr, double sigma_int,
+                        int64_t slice_len, double* out) {
+    if (m <= 0 || slice_len <= 0) return -1;
+    const int64_t n_slices = (m + slice_len - 1) / slice_len;
+    std::vector<double> dmins(n_slices), sums(n_slices);
+    for (int64_t i = 0; i < n; ++i) {
+        KdeLane a;
+        a.init(v[i], verr[i], sigma_int * sigma_int);
+        for (int64_t s = 0; s < n_slices; ++s) {
+            const int64_t j0 = s * slice_len, j1 = std::min(m, j0 + slice_len);
+            double dmin = INFINITY;
+            for (int64_t j = j0; j < j1; ++j) a.nearest(comp[j], dmin);
+            a.begin_sum(dmin);
+            for (int64_t j = j0; j < j1; ++j) a.add(comp[j]);
+            dmins[s] = dmin;
+            sums[s] = a.sum;
+        }
+        const double norm = verr[i] * verr[i] + sigma_int * sigma_int, h = 0.5 / norm;
+        double dmin = dmins[0];
+        for (int64_t s = 1; s < n_slices; ++s) dmin = std::fmin(dmin, dmins[s]);
+        const double d2 = dmin * dmin;
+        double total = 0.0;
+        for (int64_t s = 0; s < n_slices; ++s) total += sums[s] * std::exp((d2 - dmins[s] * dmins[s]) * h);
+        out[i] = -d2 * h + std::log(total / std::sqrt(2.0 * 3.14159265358979323846 * norm)) - std::log((double)m);
+    }
+    return 0;
+}

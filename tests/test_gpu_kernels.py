@@ -331,6 +331,70 @@ def test_single_stars_background(native, ctx):
     assert rel_err(cat.loglike(pos), want) < RTOL
 
 
+def _kde_err(got, want):
+    """max |got - want| / max(1, |want|): the KDE log-likelihood crosses zero, so a floor of 1 on the scale."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    return float(np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want)))) if got.size else 0.0
+
+
+def test_kde_background_matches_reference_golden(native, ctx):
+    """mcd_kde_background against background.SingleStars of the reference itself (tests/golden/single_stars.npz,
+    single_stars.py:42-77): sigma_int = 0 / 2.5 km/s, a > 1e4-sigma outlier whose other kernels all underflow, a test
+    star exactly on a comparison star, M = 1; tolerance 1e-13 relative (f64)."""
+    g = load_golden("single_stars")
+    for tag in ("s0", "s2"):
+        got = ctx.kde_background(g["comp"], g["v"], g["verr"], float(g["sigma_int_" + tag]))
+        assert _kde_err(got, g["lnlike_" + tag]) < 1e-13
+    assert _kde_err(ctx.kde_background([12.5], g["v"][:50], g["verr"][:50]), g["lnlike_m1"]) < 1e-13
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (63, 7), (64, 8), (65, 513), (1000, 5000), (200, 70001), (30000, 2000)])
+def test_kde_background_shapes_against_oracle(native, ctx, n, m):
+    """Ragged tiles (n not a multiple of 64), ragged slices (m not a multiple of 8 / of the slice length), several
+    slices per tile (small n, large m) and a single slice (large n): all against the NumPy restatement."""
+    from oracle import lnprob_numpy as oracle
+    rng = np.random.default_rng(1000 * n + m)
+    comp = rng.normal(15.0, 45.0, m)
+    v = rng.normal(0.0, 60.0, n)
+    verr = 0.05 + rng.lognormal(0.0, 0.7, n)
+    for s_int in (0.0, 1.7):
+        got = ctx.kde_background(comp, v, verr, s_int)
+        want = oracle.single_stars_background(comp, v, verr, s_int)
+        assert got.shape == (n,) and _kde_err(got, want) < 1e-13
+    again = ctx.kde_background(comp, v, verr, 1.7)
+    assert np.array_equal(got, again)                               # fixed combination order: bitwise repeatable
+
+
+def test_kde_background_edges(native, ctx):
+    """Empty test set is a no-op; no comparison stars is an error (the reference raises on the empty maximum); isolated
+    test stars 1e6 sigma away stay finite (log-sum-exp about the nearest comparison star)."""
+    assert ctx.kde_background([1.0, 2.0], [], []).shape == (0,)
+    with pytest.raises(native.NativeError):
+        ctx.kde_background([], [1.0], [1.0])
+    with pytest.raises(ValueError):
+        ctx.kde_background([1.0], [1.0, 2.0], [1.0])
+    far = ctx.kde_background([0.0, 5.0], [1.0e4], [0.01])
+    want = -0.5 * (1.0e4 - 5.0) ** 2 / 1e-4 - 0.5 * np.log(2 * np.pi * 1e-4) - np.log(2.0)
+    assert np.isfinite(far[0]) and abs(far[0] - want) <= 1e-13 * abs(want)
+
+
+def test_runner_with_single_stars_background_matches_reference(native, ctx):
+    """ConstantFit(background=SingleStars(...)): the KDE precompute (device) feeding the fixed-background kernel, against
+    lnprob of the reference on the same catalogue (tests/golden/single_stars.npz)."""
+    from mcmc_dynamics_amd import DataReader, SingleStars
+    from mcmc_dynamics_amd.analysis import ConstantFit
+    g = load_golden("single_stars")
+    data = DataReader({k: g[k] for k in ("ra", "dec", "v", "verr", "pmember")})
+    cf = ConstantFit(data, background=SingleStars(g["comp"]), context=ctx)
+    cf.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+    cf.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+    assert _kde_err(cf.lnlike_background, g["lnlike_background"]) < 1e-13
+    assert [str(x) for x in g["names"]] == list(cf.fitted_parameters)
+    assert rel_err(cf.lnprob_batch(g["values"]), g["lnprob"]) < RTOL
+    cf.close()
+
+
 def test_closed_form_known_answer(native, ctx):
     """SURVEY.md 8(c) known-answer (1): v_max = 0 => lnL = sum -1/2 [log(2 pi (e_i^2 + s^2)) + (v_i - v_sys)^2 / (e_i^2 + s^2)]
     on three hand-computable stars, through every kernel formulation; and (6): sigma = 0 is accepted by the kernels."""

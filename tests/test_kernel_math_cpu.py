@@ -101,3 +101,24 @@ def test_fast_mixtures_share_the_reference_underflow_behaviour():
     plain = emul.loglike(cat, vals, 2, centre, 0)
     assert np.all(np.isneginf(plain[:4])) and np.isfinite(plain[4:]).sum() >= 8
     assert rel_err(emul.loglike(cat, vals, 2, centre, 1), plain) < RTOL
+
+
+def test_kde_lane_math_matches_reference_golden():
+    """The KDE kernel's per-lane arithmetic (csrc/mcd_math.h: KdeLane, two passes per slice, polynomial exp) and its
+    slice combination, compiled for the host, against background.SingleStars of the reference (single_stars.py:42-77)
+    for one slice and for ragged multi-slice splits."""
+    import ctypes
+    from conftest import load_golden
+    g = load_golden("single_stars")
+    lib = emul.lib()
+    lib.emul_kde.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                             ctypes.c_double, ctypes.c_int64, ctypes.c_void_p]
+    comp, v, verr = (np.ascontiguousarray(g[k], dtype=np.float64) for k in ("comp", "v", "verr"))
+    for tag in ("s0", "s2"):
+        want = g["lnlike_" + tag]
+        for slice_len in (comp.size, 64, 8, 5):
+            out = np.empty(v.size)
+            assert lib.emul_kde(comp.size, comp.ctypes.data, v.size, v.ctypes.data, verr.ctypes.data,
+                                float(g["sigma_int_" + tag]), slice_len, out.ctypes.data) == 0
+            assert np.isfinite(out).all()
+            assert np.max(np.abs(out - want) / np.maximum(1.0, np.abs(want))) < 1e-13

@@ -173,3 +173,25 @@ def test_model_fit_family(which):
     per_star = oracle.faithful_model_cb_lnlike(_cat(g, ("density",)), lnlike_background=lnbg, no_sum=True,
                                                **{k: _named(g, row, which)[k] for k in keys})
     assert np.max(np.abs(per_star - g["lnlike_no_sum"]) / np.abs(g["lnlike_no_sum"])) < RTOL
+
+
+def test_single_stars_background_matches_reference():
+    """oracle.single_stars_background against background.SingleStars of the reference (single_stars.py:42-77):
+    sigma_int = 0 and 2.5 km/s, a > 1e4-sigma outlier, a test star exactly on a comparison star, and M = 1."""
+    g = load_golden("single_stars")
+    for tag in ("s0", "s2"):
+        got = oracle.single_stars_background(g["comp"], g["v"], g["verr"], float(g["sigma_int_" + tag]))
+        assert rel_err(got, g["lnlike_" + tag]) < 1e-15
+    assert rel_err(oracle.single_stars_background([12.5], g["v"][:50], g["verr"][:50]), g["lnlike_m1"]) < 1e-15
+    assert np.array_equal(g["lnlike_background"], g["lnlike_s0"])
+    # the fixture's lnprob rows: ConstantFit(background=SingleStars) of the reference
+    cat = {k: g[k] for k in ("ra", "dec", "v", "verr")}
+    lnbg = oracle.single_stars_background(g["comp"], g["v"], g["verr"])
+    assert np.isfinite(g["lnprior"]).sum() >= 8
+    for row, want, prior in zip(g["values"], g["lnprob"], g["lnprior"]):
+        if not np.isfinite(prior):
+            assert want == -np.inf
+            continue
+        got = oracle.faithful_constant_lnlike(cat, *row, float(g["ra_center"]), float(g["dec_center"]),
+                                              lnlike_background=lnbg, pmember=g["pmember"])
+        assert abs(got - want) <= RTOL * abs(want)
