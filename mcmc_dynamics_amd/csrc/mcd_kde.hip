@@ -9,7 +9,7 @@
 // the scalar cache; a wave evaluates 64 test stars against one slice of the comparison stars.  Per slice the wave
 // makes two passes over the (scalar-cached) slice: the nearest comparison star (largest exponent, exact), then the
 // kernel sum about it.  Slices are combined in a fixed order by kde_combine_kernel: no atomics, bitwise repeatable.
-// Bound: f64 VALU issue (about 21 f64 instructions per (i, j) pair); HBM traffic is N * 24 B + slices * M * 8 B.
+// Bound: f64 VALU issue (about 19 f64 instructions per (i, j) pair, the 2^(j/256) lookups on the LDS pipe); HBM traffic is N * 24 B + slices * M * 8 B.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -23,12 +23,18 @@ constexpr int kBlock = 256;
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = kBlock / kWave;
 
+__device__ const double kExpTabDevice[kExpTabSize] = {MCD_EXP_TABLE_VALUES};
+
 __global__ __launch_bounds__(kBlock) void kde_slice_kernel(const double* __restrict__ comp, int64_t m,
                                                             const double* __restrict__ v,
                                                             const double* __restrict__ verr, int64_t n,
                                                             double sigma_int2, int slice_len, int n_slices,
                                                             double* __restrict__ part_dmin,
                                                             double* __restrict__ part_sum) {
+    __shared__ double exptab[kExpTabSize];
+    static_assert(kExpTabSize == kBlock, "one table entry per thread");
+    exptab[threadIdx.x] = kExpTabDevice[threadIdx.x];
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -56,9 +62,9 @@ __global__ __launch_bounds__(kBlock) void kde_slice_kernel(const double* __restr
     j = 0;
     for (; j + 8 <= count; j += 8) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a.add(c[j + q]);
+        for (int q = 0; q < 8; ++q) a.add(c[j + q], exptab);
     }
-    for (; j < count; ++j) a.add(c[j]);
+    for (; j < count; ++j) a.add(c[j], exptab);
     if (i < n) {
         part_dmin[(int64_t)slice * n + i] = dmin;
         part_sum[(int64_t)slice * n + i] = a.sum;

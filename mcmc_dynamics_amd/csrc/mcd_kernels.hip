@@ -112,6 +112,8 @@ __global__ __launch_bounds__(kBlock) void prepare_walkers_kernel(const double* _
     w[W_VB] = (T)vb; w[W_SB2] = (T)(sb * sb); w[W_FB] = (T)fb;
 }
 
+__device__ const double kExpTabDevice[kExpTabSize] = {MCD_EXP_TABLE_VALUES};
+
 // ------------------------------------------------------------------------------------------------
 // main kernel (the per-chunk arithmetic lives in mcd_math.h: chunk_loglike)
 template <int MODEL, bool FREE, class T, class A, bool FAST>
@@ -123,6 +125,14 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
                                                           int uniform_len, int64_t n_records,
                                                           double* __restrict__ rerun_flag, double launch_tag) {
     constexpr int ND = record_doubles(MODEL, FREE);
+    // fast mixtures: the 2^(j/256) table of exp_tab lives in LDS (2 KiB), one entry copied per thread
+    constexpr bool kUsesExpTab = FAST && bg_kind(MODEL) != BG_NONE && sizeof(T) == 8;
+    __shared__ double exptab_lds[kUsesExpTab ? kExpTabSize : 1];
+    if constexpr (kUsesExpTab) {
+        static_assert(kExpTabSize == kBlock, "one table entry per thread");
+        exptab_lds[threadIdx.x] = kExpTabDevice[threadIdx.x];
+        __syncthreads();
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kWave - 1);
     int64_t chunk_id;
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
 
     // wave-uniform record pointer: the reads inside chunk_loglike become scalar loads
     bool denormal;
-    const double result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w, denormal);
+    const double result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
     // denormal regime of the reference's log-sum-exp met: tell the host to re-evaluate this batch with the plain kernels
     if (FAST && denormal && active) *rerun_flag = launch_tag;
     if (active) partials[w_raw * n_chunks + chunk_id] = result;

@@ -15,6 +15,9 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+
+#include "mcd_exp_table.h"
 
 #if defined(__HIPCC__)
 #define MCD_HD __host__ __device__ __forceinline__
@@ -352,34 +355,28 @@ MCD_HD double rcp_nr(double x) {
     return fma_(y, fma_(e, e, e), y);
 }
 
-// e^u = 2^k e^r with k = rint(u / ln 2), |r| <= ln2 / 2; returns the mantissa part e^r and k.
-// Polynomial: Taylor series to r^13 Chebyshev-economised to degree 11 on [-0.35, 0.35] (exact rational
-// arithmetic, then rounded to f64): approximation error 1.1e-17, 1.3e-16 with f64 Horner rounding.
-MCD_HD double exp_split(double u, int& k_out) {
-    constexpr double kLog2e = 1.442695040888963407359924681;
-    constexpr double kLn2Hi = 6.93147180369123816490e-01;    // high 32 bits of ln 2 (k * hi is exact)
-    constexpr double kLn2Lo = 1.90821492927058770002e-10;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double kf = __builtin_rint(u * kLog2e);
-#else
-    const double kf = std::nearbyint(u * kLog2e);
-#endif
-    double r = fma_(-kf, kLn2Hi, u);
-    r = fma_(-kf, kLn2Lo, r);
-    double p = 2.5116043453717065e-08;
-    p = fma_(p, r, 2.7634041305916304e-07);
-    p = fma_(p, r, 2.7557221323412594e-06);
-    p = fma_(p, r, 2.4801481568968142e-05);
-    p = fma_(p, r, 0.00019841269913226762);
-    p = fma_(p, r, 0.0013888888956048683);
-    p = fma_(p, r, 0.008333333333307623);
-    p = fma_(p, r, 0.041666666666473846);
-    p = fma_(p, r, 0.16666666666666707);
-    p = fma_(p, r, 0.500000000000002);
+// e^u = 2^e T[j] e^r with k = rint(u 256 / ln 2) = 256 e + j, |r| <= ln 2 / 512, T[j] = 2^(j/256)
+// (mcd_exp_table.h, correctly rounded).  Degree-4 Taylor polynomial on that interval: remainder r^5/120 <= 3.8e-17.
+// Returns the mantissa part T[j] e^r in [1, 2) and e.  `tab` points to the 256-entry table: LDS on the device (each
+// workgroup copies it there; the per-lane lookup is a ds_read, off the VALU), a static array on the host.
+// k comes out of the low word of u * (256 / ln 2) + 1.5 * 2^52 (round-to-nearest-even), so no v_rndne / v_cvt.
+// Requires |u| < 2^21 (callers clamp or are bounded by the host guard).  About 5 f64 VALU fewer than a table-free
+// degree-11 polynomial on |r| <= ln 2 / 2 (measured: BGFIXED 327 -> see DESIGN.md section 3.2).
+MCD_HD double exp_tab(double u, int& e_out, const double* __restrict__ tab) {
+    constexpr double kMagic = 6755399441055744.0;            // 1.5 * 2^52
+    const double shifted = fma_(u, kExpTabInvStep, kMagic);
+    const double kf = shifted - kMagic;
+    uint64_t bits;
+    std::memcpy(&bits, &shifted, sizeof bits);
+    const int k = (int)(uint32_t)bits;
+    double r = fma_(-kf, kExpTabStepHi, u);
+    r = fma_(-kf, kExpTabStepLo, r);
+    double p = fma_(r, 1.0 / 24.0, 1.0 / 6.0);
+    p = fma_(p, r, 0.5);
     p = fma_(p, r, 1.0);
     p = fma_(p, r, 1.0);
-    k_out = (int)kf;
-    return p;
+    e_out = k >> kExpTabBits;
+    return tab[k & (kExpTabSize - 1)] * p;
 }
 
 // x == +-0 tested on the bit pattern: for a wave-uniform x (SGPR pair) this stays on the scalar unit.
@@ -419,19 +416,19 @@ struct BgFixedAcc {
     // reference's expression literally, so that fast and plain results never differ by more than rounding.
     // (y_i == 0 exactly gives -inf on both paths and needs no re-run.)
     MCD_HD bool denormal() const { return emin < -1000; }
-    MCD_HD void add_density(double d, double n, double rho, double f, double nbp) {
-        add<false>(d, n, rho, f, nbp);           // f_back is a per-walker (VGPR) value here
+    MCD_HD void add_density(double d, double n, double rho, double f, double nbp, const double* __restrict__ exptab) {
+        add<false>(d, n, rho, f, nbp, exptab);   // f_back is a per-walker (VGPR) value here
         lden.mul(rho + f);
     }
     template <bool UNIFORM_OMP = true>
-    MCD_HD void add(double d, double n, double p, double omp, double nbp) {
+    MCD_HD void add(double d, double n, double p, double omp, double nbp, const double* __restrict__ exptab) {
         const double g = rsqrt_nr(n);
         const double dg = d * g;
-        // |u| <= 1e9 by the host guard (|v - v_los| / sqrt(norm) <= 4e4, |lnL_bg| <= 1e5): k fits an int and e^u
-        // is an exact 0 long before the range reduction loses accuracy.
-        const double u = fma_sgpr_addend(-0.5 * dg, dg, nbp);
+        // u <= 1e5 by the host guard (|lnL_bg| <= 1e5); below -1100 e^u is an exact 0 in f64 (as in the reference),
+        // and the clamp keeps 256 u / ln 2 inside the int range of exp_tab.
+        const double u = fmax_(fma_sgpr_addend(-0.5 * dg, dg, nbp), -1100.0);
         int k;
-        const double er = exp_split(u, k);
+        const double er = exp_tab(u, k, exptab);
         // y = (1 - p) + p g e^r 2^k.  k > 1000 (cluster likelihood e^693 times the background's) is carried in the
         // integer part of the product: there the (1 - p) term is below 2^-900 of y and drops out exactly as in f64.
         // k < -1074 underflows inside ldexp; with p == 1 exactly that gives y = 0 and lnL = -inf, which is also what
@@ -459,14 +456,14 @@ struct BgGaussAcc {
     int emin;              // as BgFixedAcc::emin: y_i < 2^-1000 needs the undamped component to be exactly zero
     MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); emin = 0; }
     MCD_HD bool denormal() const { return emin < -1000; }
-    MCD_HD void add(double d, double n, double db, double nb, double rho, double f) {
+    MCD_HD void add(double d, double n, double db, double nb, double rho, double f, const double* __restrict__ exptab) {
         const double g = rsqrt_nr(n), gb = rsqrt_nr(nb);
         const double dg = d * g, dbg = db * gb;
         const double w = dg * dg, wb = dbg * dbg;
         const bool cluster_big = w <= wb;                 // cluster exponent -w/2 is the larger one
         const double delta = cluster_big ? (wb - w) : (w - wb);
-        int k;                                            // delta <= 2e9 by the host guard
-        const double er = exp_split(-0.5 * delta, k);
+        int k;                                            // e^-1100 == 0 in f64; the clamp keeps k inside int range
+        const double er = exp_tab(fmax_(-0.5 * delta, -1100.0), k, exptab);
         const double e = ldexp_(er, k);                    // k <= 0: underflows to 0 inside ldexp
         const double a = rho * g, b = f * gb;
         // if the undamped component is exactly zero (f_back = 0 or density = 0) and e^{-delta} underflows, y = 0 and
@@ -509,12 +506,12 @@ struct KdeLane {
     }
     MCD_HD void nearest(double c, double& dmin) const { dmin = fmin_(dmin, fabs_(c - v)); }
     MCD_HD void begin_sum(double dmin) { d2min = dmin * dmin; sum = 0.0; }
-    MCD_HD void add(double c) {
+    MCD_HD void add(double c, const double* __restrict__ exptab) {
         const double d = c - v;
         // exp(u) == 0 in f64 below u = -745.2; the clamp keeps k inside int range for far outliers
         const double u = fmax_(fma_(-d, d, d2min) * h, -800.0);
         int k;
-        const double er = exp_split(u, k);
+        const double er = exp_tab(u, k, exptab);
         sum += ldexp_(er, k);
     }
 };
@@ -577,8 +574,10 @@ MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T&
 }
 
 // `denormal` is set when a fast mixture path met the denormal regime described at BgFixedAcc::denormal().
+// `exptab`: the 2^(j/256) table of exp_tab (read by the fast mixture paths only; may be null otherwise).
 template <int MODEL, bool FREE, class T, class A, bool FAST>
-MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w, bool& denormal) {
+MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w, bool& denormal,
+                            const double* __restrict__ exptab) {
     constexpr int ND = record_doubles(MODEL, FREE);
     denormal = false;
     constexpr int XB = geometry_doubles(MODEL, FREE);      // first background slot of a record
@@ -663,14 +662,14 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 const double* rr = r + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
-                acc.add(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3]);
+                acc.add(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3], exptab);
             }
             acc.rescale();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
-            acc.add(d, n, r[XB + 1], r[XB + 2], r[XB + 3]);
+            acc.add(d, n, r[XB + 1], r[XB + 2], r[XB + 3], exptab);
             acc.rescale();
         }
         result = acc.finish();
@@ -685,14 +684,14 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 const double* rr = r + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
-                acc.add_density(d, n, rr[XB + 2], w.fb, rr[XB + 1]);
+                acc.add_density(d, n, rr[XB + 2], w.fb, rr[XB + 1], exptab);
             }
             acc.rescale_density();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
-            acc.add_density(d, n, r[XB + 2], w.fb, r[XB + 1]);
+            acc.add_density(d, n, r[XB + 2], w.fb, r[XB + 1], exptab);
             acc.rescale_density();
         }
         result = acc.finish_density();
@@ -707,14 +706,14 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 const double* rr = r + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
-                acc.add(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb);
+                acc.add(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb, exptab);
             }
             acc.rescale();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
-            acc.add(d, n, r[0] - w.vb, r[1] + w.sb2, r[XB], w.fb);
+            acc.add(d, n, r[0] - w.vb, r[1] + w.sb2, r[XB], w.fb, exptab);
             acc.rescale();
         }
         result = acc.finish(count);

@@ -9,6 +9,8 @@
 
 using namespace mcd;
 
+static const double kExpTabHost[kExpTabSize] = {MCD_EXP_TABLE_VALUES};
+
 template <int MODEL, bool FREE, bool FAST>
 static void run(int64_t n, const double* recs, const double* wpar, int64_t W, int64_t chunk_len, double* out) {
     constexpr int ND = record_doubles(MODEL, FREE);
@@ -20,7 +22,7 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
         for (int64_t s = 0; s < n; s += chunk_len) {
             const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
             bool denormal;
-            total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c, denormal);
+            total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c, denormal, kExpTabHost);
             rerun = rerun || denormal;
         }
         if (FAST && rerun) {                          // what the library does: the batch is re-evaluated with the plain kernels
@@ -28,7 +30,7 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
             for (int64_t s = 0; s < n; s += chunk_len) {
                 const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
                 bool dummy;
-                total += chunk_loglike<MODEL, FREE, double, double, false>(recs + s * ND, count, c, dummy);
+                total += chunk_loglike<MODEL, FREE, double, double, false>(recs + s * ND, count, c, dummy, kExpTabHost);
             }
             out[w] = total;
             continue;
@@ -103,7 +105,7 @@ extern "C" int emul_kde(int64_t m, const double* comp, int64_t n, const double* 
             double dmin = INFINITY;
             for (int64_t j = j0; j < j1; ++j) a.nearest(comp[j], dmin);
             a.begin_sum(dmin);
-            for (int64_t j = j0; j < j1; ++j) a.add(comp[j]);
+            for (int64_t j = j0; j < j1; ++j) a.add(comp[j], kExpTabHost);
             dmins[s] = dmin;
             sums[s] = a.sum;
         }

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void lane_walker_kernel(const double* __res
     const int64_t begin = chunk * chunk_len;
     const int count = (int)((n - begin) < chunk_len ? (n - begin) : chunk_len);
     bool denormal;
-    const double r = chunk_loglike<MODEL_CONST, false, double, double, true>(recs + begin * 4, count, c, denormal);
+    const double r = chunk_loglike<MODEL_CONST, false, double, double, true>(recs + begin * 4, count, c, denormal, nullptr);
     if (w < W) partials[chunk * W + w] = r + 0.5 * count * kLn2Pi;              // same convention as variant A
 }
 
