@@ -43,10 +43,16 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
         if (bg == BG_FIXED) {
             const double pm = pmember[i];
             if (!(pm >= 0.0 && pm <= 1.0)) ok = false;
+            // lnL_bg < -690: the cluster term can exceed 2^1000 times the background's and is then carried in the
+            // exponent (BgFixedAcc::add), which drops (1 - p): only valid while p 2^1000 dwarfs 1.  A zero or
+            // vanishing prior there also makes the reference's log-sum-exp underflow (runner.py:282-284 gives -inf for
+            // p == 0): the plain kernels reproduce that literally.
+            if (lnbg[i] < -690.0 && !(pm >= 0x1p-700)) ok = false;
         }
         if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) {
             const double rho = density[i];
             if (!(std::isfinite(rho) && rho >= 0.0)) ok = false;
+            if (bg == BG_FIXED_DENSITY && lnbg[i] < -690.0 && !(rho >= 0x1p-700)) ok = false;   // as for pmember above
             r_min = std::min(r_min, rho);
             r_max = std::max(r_max, rho);
         }
@@ -60,7 +66,7 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
 // Fast paths (f64 only) are valid while their intermediate products stay far from over/underflow.
 //   CONST   (fraction tree over 8 stars + log product): 2^-60 <= verr^2 + sigma^2 <= 2^60, |v - v_los| < 2^58
 //   BGFIXED / BGGAUSS (rsqrt + one exp + log product):  2^-200 <= norm <= 2^200, |v - v_los|^2 / norm <= 1.6e9, finite columns,
-//            lnlike_bg > -1e5, 0 <= pmember <= 1;  density >= 0, f_back >= 0, 2^-100 <= density + f_back <= 2^100
+//            lnlike_bg > -1e5, 0 <= pmember <= 1 (>= 2^-700 where lnlike_bg < -690);  density >= 0 (likewise), f_back >= 0, 2^-100 <= density + f_back <= 2^100
 // Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
 // expressions term by term.
 inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,

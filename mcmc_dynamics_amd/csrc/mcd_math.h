@@ -146,6 +146,18 @@ MCD_HD double fma_sgpr_addend(double a, double b, double c) {
 #endif
 }
 
+// max(x, lo) for an x that is already an arithmetic result (never a signalling NaN): the plain v_max_f64.  The
+// builtin fmax after an inline-asm producer makes hipcc insert a canonicalising v_max_f64 x, x, x first.
+MCD_HD double fmax_raw(double x, double lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(lo));
+    return r;
+#else
+    return std::fmax(x, lo);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // sum of logs as the log of a running product with explicit exponent tracking:
 //   sum_i log(x_i) = log(prod_i m_i) + ln2 * sum_i e_i .
@@ -426,7 +438,7 @@ struct BgFixedAcc {
         const double dg = d * g;
         // u <= 1e5 by the host guard (|lnL_bg| <= 1e5); below -1100 e^u is an exact 0 in f64 (as in the reference),
         // and the clamp keeps 256 u / ln 2 inside the int range of exp_tab.
-        const double u = fmax_(fma_sgpr_addend(-0.5 * dg, dg, nbp), -1100.0);
+        const double u = fmax_raw(fma_sgpr_addend(-0.5 * dg, dg, nbp), -1100.0);
         int k;
         const double er = exp_tab(u, k, exptab);
         // y = (1 - p) + p g e^r 2^k.  k > 1000 (cluster likelihood e^693 times the background's) is carried in the

@@ -122,3 +122,24 @@ def test_kde_lane_math_matches_reference_golden():
                                 float(g["sigma_int_" + tag]), slice_len, out.ctypes.data) == 0
             assert np.isfinite(out).all()
             assert np.max(np.abs(out - want) / np.maximum(1.0, np.abs(want))) < 1e-13
+
+
+def test_vanishing_prior_with_extreme_background_takes_the_plain_path():
+    """pmember == 0 (or 1e-300) on a star whose background likelihood is e^-2000: the reference's log-sum-exp about the
+    cluster exponent underflows (runner.py:282-284: -inf for p == 0); the exponent-carrying fast path would return the
+    mathematically exact value instead, so the range guard must send such catalogues to the plain kernels."""
+    g = load_golden("constant_bg_gaussian_fixed")
+    centre = (float(g["ra_center"]), float(g["dec_center"]))
+    rows = g["values"][np.isfinite(g["lnprior"])]
+    cat = {k: g[k].copy() for k in ("ra", "dec", "v", "verr", "pmember")}
+    cat["lnlike_bg"] = g["lnlike_background"].copy()
+    cat["lnlike_bg"][10] = -2000.0
+    for p, admitted in ((0.0, False), (1e-300, False), (1e-30, True), (0.5, True), (1.0, True)):
+        cat["pmember"][10] = p
+        assert emul.fast_guard(cat, rows, 1, centre) == admitted
+        if admitted:
+            assert rel_err(emul.loglike(cat, rows, 1, centre, 1), emul.loglike(cat, rows, 1, centre, 0)) < RTOL
+    cat["pmember"][10] = 0.0
+    cat["lnlike_bg"][10] = -600.0                       # no exponent carry above -690: any prior is fine
+    assert emul.fast_guard(cat, rows, 1, centre)
+    assert rel_err(emul.loglike(cat, rows, 1, centre, 1), emul.loglike(cat, rows, 1, centre, 0)) < RTOL
