@@ -22,9 +22,9 @@ done
 timeout -k 10 200 python tools/kde_probe.py > $O/kde_probe_$TAG.json 2> $O/kde_probe.err || exit 1
 echo "benches done"
 rm -rf $O/prof_${TAG}_c3 $O/prof_${TAG}_c2 $O/pmc_fetch_$TAG $O/pmc_write_$TAG
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c3/runc -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c3.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c2/runc -- python3 bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c2.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c3 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c3.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c2 -- python3 bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c2.log 2>&1 || exit 1
 echo "kernel traces done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG/runc -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc > $O/pmc_fetch_$TAG.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG/runc -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc > $O/pmc_write_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc > $O/pmc_fetch_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc > $O/pmc_write_$TAG.log 2>&1 || exit 1
 echo "sweep $TAG complete"

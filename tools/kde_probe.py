@@ -45,7 +45,7 @@ def main():
     k = float(np.median(kernel_ms))
     print(json.dumps({"what": "kde_background", "stars": a.stars, "comp": a.comp, "kernel_ms": k,
                       "pairs_per_s": pairs / (k * 1e-3), "call_wall_ms": float(np.median(wall_ms)),
-                      "f64_valu_slots_per_pair": 24, "cpu_port_pairs_per_s": ns * a.comp / cpu_s,
+                      "valu_slots_per_pair": 19, "cpu_port_pairs_per_s": ns * a.comp / cpu_s,
                       "cpu_sample_stars": ns, "max_err_vs_port": err}))
 
 
