@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kBlock) void prepare_walkers_kernel(const double* _
 }
 
 __device__ const double kExpTabDevice[kExpTabSize] = {MCD_EXP_TABLE_VALUES};
+__device__ const double kExpTabSqrt2Device[kExpTabSize] = {MCD_EXP_TABLE_SQRT2_VALUES};
 
 // ------------------------------------------------------------------------------------------------
 // main kernel (the per-chunk arithmetic lives in mcd_math.h: chunk_loglike)
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
     __shared__ double exptab_lds[kUsesExpTab ? kExpTabSize : 1];
     if constexpr (kUsesExpTab) {
         static_assert(kExpTabSize == kBlock, "one table entry per thread");
-        exptab_lds[threadIdx.x] = kExpTabDevice[threadIdx.x];
+        exptab_lds[threadIdx.x] = exp_table_is_sqrt2_scaled(MODEL) ? kExpTabSqrt2Device[threadIdx.x] : kExpTabDevice[threadIdx.x];
         __syncthreads();
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -146,6 +146,17 @@ MCD_HD double fma_sgpr_addend(double a, double b, double c) {
 #endif
 }
 
+// -(a * b) + c, same SGPR-addend form (the negation is a source modifier)
+MCD_HD double fnma_sgpr_addend(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#else
+    return std::fma(-a, b, c);
+#endif
+}
+
 // max(x, lo) for an x that is already an arithmetic result (never a signalling NaN): the plain v_max_f64.  The
 // builtin fmax after an inline-asm producer makes hipcc insert a canonicalising v_max_f64 x, x, x first.
 MCD_HD double fmax_raw(double x, double lo) {
@@ -432,13 +443,16 @@ struct BgFixedAcc {
         add<false>(d, n, rho, f, nbp, exptab);   // f_back is a per-walker (VGPR) value here
         lden.mul(rho + f);
     }
-    template <bool UNIFORM_OMP = true>
+    // HALVED: the caller passes 2 n instead of n and the table sqrt(2) 2^(j/256) (MCD_EXP_TABLE_SQRT2_VALUES):
+    //   gh = (2 n)^(-1/2) = g / sqrt(2),  -(d gh)^2 = -1/2 d^2 g^2,  p gh (sqrt(2) T[j]) e^r = p g T[j] e^r,
+    // which drops the multiplication by -1/2 (2 n = 2 verr^2 + 2 sigma^2 is formed by one FMA, like n by one add).
+    template <bool UNIFORM_OMP = true, bool HALVED = false>
     MCD_HD void add(double d, double n, double p, double omp, double nbp, const double* __restrict__ exptab) {
         const double g = rsqrt_nr(n);
         const double dg = d * g;
         // u <= 1e5 by the host guard (|lnL_bg| <= 1e5); below -1100 e^u is an exact 0 in f64 (as in the reference),
         // and the clamp keeps 256 u / ln 2 inside the int range of exp_tab.
-        const double u = fmax_raw(fma_sgpr_addend(-0.5 * dg, dg, nbp), -1100.0);
+        const double u = fmax_raw(HALVED ? fnma_sgpr_addend(dg, dg, nbp) : fma_sgpr_addend(-0.5 * dg, dg, nbp), -1100.0);
         int k;
         const double er = exp_tab(u, k, exptab);
         // y = (1 - p) + p g e^r 2^k.  k > 1000 (cluster likelihood e^693 times the background's) is carried in the
@@ -586,7 +600,10 @@ MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T&
 }
 
 // `denormal` is set when a fast mixture path met the denormal regime described at BgFixedAcc::denormal().
-// `exptab`: the 2^(j/256) table of exp_tab (read by the fast mixture paths only; may be null otherwise).
+// `exptab`: the 2^(j/256) table of exp_tab (read by the fast mixture paths only; may be null otherwise);
+// for MODEL_BGFIXED it is the sqrt(2)-scaled table (exp_table_is_sqrt2_scaled).
+MCD_HD constexpr bool exp_table_is_sqrt2_scaled(int model) { return model == MODEL_BGFIXED; }
+
 template <int MODEL, bool FREE, class T, class A, bool FAST>
 MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w, bool& denormal,
                             const double* __restrict__ exptab) {
@@ -665,6 +682,10 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         }
         result = -0.5 * ((double)count * kLn2Pi + (double)sum_log + (double)sum_q);
     } else if constexpr (BG == BG_FIXED && FAST) {
+        // MODEL_BGFIXED has norm = verr^2 + sigma^2 (constant.py:52-74): the accumulator takes 2 norm (HALVED form) and
+        // `exptab` is then the sqrt(2)-scaled table; star_d_n's own norm is dead code there.
+        constexpr bool HALVED = MODEL == MODEL_BGFIXED;
+        const double s2x2 = (double)w.s2 + (double)w.s2;
         BgFixedAcc acc;
         acc.init();
         const int n4 = count >> 2;
@@ -674,14 +695,16 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 const double* rr = r + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
-                acc.add(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3], exptab);
+                if constexpr (HALVED) n = fma_(2.0, rr[1], s2x2);
+                acc.add<true, HALVED>(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3], exptab);
             }
             acc.rescale();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
-            acc.add(d, n, r[XB + 1], r[XB + 2], r[XB + 3], exptab);
+            if constexpr (HALVED) n = fma_(2.0, r[1], s2x2);
+            acc.add<true, HALVED>(d, n, r[XB + 1], r[XB + 2], r[XB + 3], exptab);
             acc.rescale();
         }
         result = acc.finish();

@@ -10,6 +10,7 @@
 using namespace mcd;
 
 static const double kExpTabHost[kExpTabSize] = {MCD_EXP_TABLE_VALUES};
+static const double kExpTabSqrt2Host[kExpTabSize] = {MCD_EXP_TABLE_SQRT2_VALUES};
 
 template <int MODEL, bool FREE, bool FAST>
 static void run(int64_t n, const double* recs, const double* wpar, int64_t W, int64_t chunk_len, double* out) {
@@ -22,7 +23,7 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
         for (int64_t s = 0; s < n; s += chunk_len) {
             const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
             bool denormal;
-            total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c, denormal, kExpTabHost);
+            total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c, denormal, exp_table_is_sqrt2_scaled(MODEL) ? kExpTabSqrt2Host : kExpTabHost);
             rerun = rerun || denormal;
         }
         if (FAST && rerun) {                          // what the library does: the batch is re-evaluated with the plain kernels

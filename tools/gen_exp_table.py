@@ -14,6 +14,7 @@ N = 256
 def main():
     ln2 = Decimal(2).ln()
     rows = [float((ln2 * j / N).exp()).hex() for j in range(N)]          # Decimal -> float rounds correctly
+    rows2 = [float((ln2 * (Decimal(j) / N + Decimal("0.5"))).exp()).hex() for j in range(N)]   # sqrt(2) 2^(j/256)
     step = ln2 / N
     bits = struct.unpack("<Q", struct.pack("<d", float(step)))[0] & ~((1 << 20) - 1)   # keep 32 mantissa bits
     hi = struct.unpack("<d", struct.pack("<Q", bits))[0]
@@ -30,6 +31,10 @@ def main():
         f.write("#define MCD_EXP_TABLE_VALUES \\\n")
         for i in range(0, N, 4):
             f.write("    " + ", ".join(rows[i:i + 4]) + (", \\\n" if i + 4 < N else "\n"))
+        f.write("\n// sqrt(2) * 2^(j/256): the table of the BGFIXED kernel, which works with g / sqrt(2) = (2 n)^(-1/2)\n")
+        f.write("#define MCD_EXP_TABLE_SQRT2_VALUES \\\n")
+        for i in range(0, N, 4):
+            f.write("    " + ", ".join(rows2[i:i + 4]) + (", \\\n" if i + 4 < N else "\n"))
         f.write("\n}  // namespace mcd\n")
 
 
