@@ -32,6 +32,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, c
 #   per SIMD = 2.33 ns on the fully occupied chip (tools/valu_rate_probe.hip).
 VALU_SLOTS_PER_TERM = {"const": 9.11, "bgfixed": 34.52, "bggauss": 56.80, "profile": 27.91}
 VALU_SLOT_NS = 2.33
+COLLECTIVE_TIMEOUT_S = 180
 N_SIMD = 256 * 4
 
 WORKLOADS = {
@@ -277,8 +278,32 @@ def main():
         bytes_per_term = bytes_per_term if args.precision == "f64" else bytes_per_term // 2
 
     gpu_cat = build_catalog(native, ctx, synthetic, None, cat, model, args.precision, bin_offsets)
-    gpu_cat.set_option("timing", 2)
     gpu_cat.upload_params(pos)
+    abandoned = None
+    if dist is not None and not rccl_note.startswith("unavailable"):
+        # Watchdog for the first collective (RCCL builds its xGMI rings lazily inside it): a rank whose all-reduce has
+        # not completed after COLLECTIVE_TIMEOUT_S abandons that context and every rank drops to the degraded mode, so
+        # that a fabric problem yields a marked bench line instead of a hung job.
+        import threading
+        import torch
+        done = threading.Event()
+
+        def first_step():
+            gpu_cat.enqueue()
+            gpu_cat.sync()
+            done.set()
+        worker = threading.Thread(target=first_step, daemon=True)
+        worker.start()
+        worker.join(COLLECTIVE_TIMEOUT_S)
+        flag = torch.tensor([1 if done.is_set() else 0], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            abandoned = (gpu_cat, ctx)                   # never closed: its stream may be blocked for good
+            rccl_note = "unavailable: first all-reduce did not complete within {0} s on some rank".format(COLLECTIVE_TIMEOUT_S)
+            ctx = native.Context(n_devices=1, device_ids=[local_rank])
+            gpu_cat = build_catalog(native, ctx, synthetic, None, cat, model, args.precision, bin_offsets)
+            gpu_cat.upload_params(pos)
+    gpu_cat.set_option("timing", 2)
 
     def barrier():
         gpu_cat.sync()
@@ -344,6 +369,8 @@ def main():
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+        if abandoned is not None:
+            os._exit(0)                                  # skip destructors of the abandoned (possibly blocked) context
         return
 
     terms_per_step = float(total_stars) * n_walkers
@@ -352,12 +379,13 @@ def main():
     local_terms = float(len(cat["v"])) * n_walkers
     achieved = local_terms * bytes_per_term / kernel_s / 1e9
 
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get(args.workload)
-    except Exception:
-        pass
+    traffic = None                                    # PMC bytes per launch, measured for the default shape of a workload
+    if args.stars is None and args.walkers is None and args.precision == "f64" and not strong:
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(args.workload)
+        except Exception:
+            pass
 
     out = {
         "metric": "star-walker log-L terms/sec", "value": value, "unit": "terms/s",
@@ -411,6 +439,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if abandoned is not None:
+        os._exit(0)
 
 
 if __name__ == "__main__":
