@@ -201,18 +201,24 @@ struct LogProduct {
         p *= m;
         e32 += ex;
     }
-    // as mul_any, additionally keeping the smallest binary exponent seen (one v_min_i32): a factor below 2^-1000
-    // marks the denormal regime of the reference's log-sum-exp (see BgFixedAcc::denormal)
+    // as mul_any for x >= 0, additionally keeping the smallest BIASED exponent field seen (one v_min_i32): a field
+    // below kTrackFloor (x < 2^-1000, which includes denormals and an exact 0) marks the regime where the reference's
+    // log-sum-exp works on denormal numbers (see BgFixedAcc::denormal).  The exponent comes from the bit field (one
+    // shift) instead of v_frexp_exp; for a denormal or zero x it is off, but those batches are re-evaluated anyway.
+    static constexpr int kTrackInit = 2047, kTrackFloor = 23;      // 23 - 1023 = -1000
     MCD_HD void mul_any_track(double x, int& emin) {
-        int ex;
+        uint64_t bits;
+        std::memcpy(&bits, &x, sizeof bits);
+        const int bx = (int)(bits >> 52);                            // sign bit is 0
 #if defined(__HIP_DEVICE_COMPILE__)
-        double m = __builtin_frexp(x, &ex);
+        double m = __builtin_amdgcn_frexp_mant(x);
 #else
-        double m = std::frexp(x, &ex);
+        int unused;
+        double m = std::frexp(x, &unused);
 #endif
         p *= m;
-        e32 += ex;
-        emin = ex < emin ? ex : emin;
+        e32 += bx - 1022;
+        emin = bx < emin ? bx : emin;
     }
     MCD_HD double value() {
         rescale();
@@ -430,15 +436,16 @@ MCD_HD double fmax_(double a, double b) {
 struct BgFixedAcc {
     LogProduct l;          // sum log y_i   (sum b_i is walker-independent: added once per parameter set by the reduce kernel)
     LogProduct lden;       // BG_FIXED_DENSITY: sum log(rho_i + f)
-    int emin;              // smallest binary exponent of any mixture value y_i (see denormal())
-    MCD_HD void init() { l.init(); lden.init(); emin = 0; }
+    int emin;              // smallest biased exponent of any mixture value y_i (see denormal())
+    MCD_HD void init() { l.init(); lden.init(); emin = LogProduct::kTrackInit; }
     // True when some y_i fell below 2^-1000.  Since 1 - p >= 2^-53 unless p == 1 exactly, that only happens for a star
     // with pmember == 1 (or a walker with f_back == 0) whose cluster term is e^-693 or less: there the reference's
     // log-sum-exp (runner.py:282-284) works on DENORMAL numbers and its result carries their rounding noise
     // (1e-7 .. 1e-2 absolute).  The library then re-evaluates the batch with the plain kernels, which execute the
     // reference's expression literally, so that fast and plain results never differ by more than rounding.
-    // (y_i == 0 exactly gives -inf on both paths and needs no re-run.)
-    MCD_HD bool denormal() const { return emin < -1000; }
+    // An exact y_i == 0 is flagged too: the reference applies its prefactors inside the exponent (e^{m - M}), this path
+    // outside (g e^u), so the two underflow at slightly different outliers (found by tools/fuzz_gpu.py).
+    MCD_HD bool denormal() const { return emin < LogProduct::kTrackFloor; }
     MCD_HD void add_density(double d, double n, double rho, double f, double nbp, const double* __restrict__ exptab) {
         add<false>(d, n, rho, f, nbp, exptab);   // f_back is a per-walker (VGPR) value here
         lden.mul(rho + f);
@@ -480,8 +487,8 @@ struct BgGaussAcc {
     LogProduct ly;         // sum log y_i
     LogProduct lden;       // sum log(rho_i + f)
     int emin;              // as BgFixedAcc::emin: y_i < 2^-1000 needs the undamped component to be exactly zero
-    MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); emin = 0; }
-    MCD_HD bool denormal() const { return emin < -1000; }
+    MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); emin = LogProduct::kTrackInit; }
+    MCD_HD bool denormal() const { return emin < LogProduct::kTrackFloor; }
     MCD_HD void add(double d, double n, double db, double nb, double rho, double f, const double* __restrict__ exptab) {
         const double g = rsqrt_nr(n), gb = rsqrt_nr(nb);
         const double dg = d * g, dbg = db * gb;

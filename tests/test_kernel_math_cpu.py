@@ -143,3 +143,22 @@ def test_vanishing_prior_with_extreme_background_takes_the_plain_path():
     cat["lnlike_bg"][10] = -600.0                       # no exponent carry above -690: any prior is fine
     assert emul.fast_guard(cat, rows, 1, centre)
     assert rel_err(emul.loglike(cat, rows, 1, centre, 1), emul.loglike(cat, rows, 1, centre, 0)) < RTOL
+
+
+@pytest.mark.parametrize("seed,model", [(1275109, 2), (1283548, 2)])
+def test_underflow_window_between_the_two_formulations(seed, model):
+    """Found by tools/fuzz_gpu.py: a star with density == 0 whose background exponent lies ~745 below the cluster's.
+    The reference keeps the prefactors inside the exponent (exp(lb - lc) is still a denormal: finite result), the
+    single-exp formulation applies them outside (f g_b * exp(-delta/2) with the exp already flushed to 0).  An exact
+    zero mixture value therefore has to trigger the re-evaluation with the plain kernels, like a denormal one."""
+    from test_guard_random_cpu import CENTRE, random_case
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 1500))
+    w = int(rng.integers(1, 200))
+    cat, params = random_case(rng, model, n=n, w=w)
+    assert emul.fast_guard(cat, params, model, CENTRE)
+    plain = emul.loglike(cat, params, model, CENTRE, 0, chunk_len=64)
+    fast = emul.loglike(cat, params, model, CENTRE, 1, chunk_len=64)
+    assert np.array_equal(np.isfinite(plain), np.isfinite(fast))
+    ok = np.isfinite(plain)
+    assert rel_err(fast[ok], plain[ok]) < 1e-11

@@ -1,0 +1,85 @@
+"""Randomised fast-path vs plain-path campaign on the device (longer version of
+tests/test_gpu_kernels.py::test_fast_and_plain_kernels_agree_over_wide_ranges).
+
+    python tools/fuzz_gpu.py [--trials 400] [--seed 1] [--seconds 240]
+
+For every model (fixed and free centre) random catalogues / walker tables spanning many orders of magnitude are evaluated
+with the guarded fast path and with the plain (reference-literal) kernels; any disagreement in the finite / -inf pattern
+or beyond 1e-11 relative is printed with its seed.  Exit status 1 if any trial disagreed."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from mcmc_dynamics_amd import _native as native  # noqa: E402
+from test_guard_random_cpu import CENTRE, random_case  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=240.0)
+    a = ap.parse_args()
+    ctx = native.default_context()
+    t0 = time.time()
+    bad = total = reruns = admitted_inf = 0
+    worst = 0.0
+    for trial in range(a.trials):
+        if time.time() - t0 > a.seconds:
+            break
+        for model in range(6):
+            for free in (False, True):
+                if free and model == 4:
+                    continue
+                seed = a.seed * 1000003 + trial * 97 + model * 7 + int(free)
+                rng = np.random.default_rng(seed)
+                n = int(rng.integers(1, 1500))
+                w = int(rng.integers(1, 200))
+                cat, params = random_case(rng, model, n=n, w=w)
+                kw = {}
+                if model == 1:
+                    kw = dict(lnlike_bg=cat["lnlike_bg"], pmember=cat["pmember"])
+                elif model in (2, 4):
+                    kw = dict(density=cat["density"])
+                elif model == 5:
+                    kw = dict(lnlike_bg=cat["lnlike_bg"], density=cat["density"])
+                centre = CENTRE
+                if free:
+                    head = 6 if model >= 3 else 4
+                    cc = np.column_stack([CENTRE[0] + rng.normal(0, 0.01, len(params)),
+                                          CENTRE[1] + rng.normal(0, 0.01, len(params))])
+                    params = np.hstack([params[:, :head], cc, params[:, head:]])
+                    centre = None
+                g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model, centre=centre, **kw)
+                fast = g.loglike(params)
+                reruns += g.rerun_count
+                g.set_option("fast_path", 0)
+                plain = g.loglike(params)
+                g.close()
+                total += 1
+                same = np.array_equal(np.isfinite(fast), np.isfinite(plain)) and \
+                    np.array_equal(np.isnan(fast), np.isnan(plain))
+                ok = np.isfinite(plain) & np.isfinite(fast)
+                # every term is O(1 .. 10): a total that cancels to less than n is judged on the scale n
+                err = float(np.max(np.abs(fast[ok] - plain[ok]) / np.maximum(np.abs(plain[ok]), float(n)))) if ok.any() else 0.0
+                admitted_inf += int(np.isneginf(plain).sum())
+                worst = max(worst, err)
+                if not same or err > 1e-11:
+                    bad += 1
+                    print("MISMATCH seed", seed, "model", model, "free", free, "n", n, "w", w, "pattern_same", same, "err", err,
+                          flush=True)
+        if trial % 20 == 0:
+            print("trial", trial, "cases", total, "bad", bad, "worst rel err", worst, "reruns", reruns, "-inf walkers", admitted_inf,
+                  "elapsed %.0f s" % (time.time() - t0), flush=True)
+    print("DONE cases", total, "bad", bad, "worst rel err", worst, "reruns", reruns, "-inf walkers", admitted_inf, flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
