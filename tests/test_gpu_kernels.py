@@ -425,8 +425,8 @@ def test_fast_and_plain_kernels_agree_over_wide_ranges(native, ctx, model):
     from test_guard_random_cpu import CENTRE, MODELS, random_case
     rng = np.random.default_rng(500 + model)
     reruns = 0
-    for trial in range(25):
-        cat, params = random_case(rng, model, n=500, w=70)
+    for trial in range(200):
+        cat, params = random_case(rng, model, n=int(rng.integers(1, 900)), w=int(rng.integers(1, 140)))
         kw = {}
         if model == 1:
             kw = dict(lnlike_bg=cat["lnlike_bg"], pmember=cat["pmember"])
@@ -443,7 +443,8 @@ def test_fast_and_plain_kernels_agree_over_wide_ranges(native, ctx, model):
         g.close()
         assert np.array_equal(np.isfinite(fast), np.isfinite(plain)), (trial, fast, plain)
         ok = np.isfinite(plain)
-        assert rel_err(fast[ok], plain[ok]) < 1e-11, trial
+        # every term is O(1 .. 10): a total that cancels below the number of stars is judged on that scale
+        assert np.max(np.abs(fast[ok] - plain[ok]) / np.maximum(np.abs(plain[ok]), len(cat["v"])), initial=0.0) < 1e-11, trial
     assert reruns == 0 or model in (1, 2, 4, 5)          # only mixtures can meet the reference's denormal regime
 
 
@@ -453,8 +454,8 @@ def test_fast_and_plain_kernels_agree_free_centre(native, ctx, model):
     from test_guard_random_cpu import CENTRE, random_case
     rng = np.random.default_rng(900 + model)
     head = 6 if model >= 3 else 4
-    for trial in range(8):
-        cat, params = random_case(rng, model, n=400, w=66)
+    for trial in range(60):
+        cat, params = random_case(rng, model, n=int(rng.integers(1, 700)), w=int(rng.integers(1, 100)))
         centre_cols = np.column_stack([CENTRE[0] + rng.normal(0, 0.01, len(params)), CENTRE[1] + rng.normal(0, 0.01, len(params))])
         params = np.hstack([params[:, :head], centre_cols, params[:, head:]])
         kw = {}
@@ -471,7 +472,7 @@ def test_fast_and_plain_kernels_agree_free_centre(native, ctx, model):
         g.close()
         assert np.array_equal(np.isfinite(fast), np.isfinite(plain)), trial
         ok = np.isfinite(plain)
-        assert rel_err(fast[ok], plain[ok]) < 1e-11, trial
+        assert np.max(np.abs(fast[ok] - plain[ok]) / np.maximum(np.abs(plain[ok]), len(cat["v"])), initial=0.0) < 1e-11, trial
 
 
 @pytest.mark.parametrize("model", [1, 2, 5])

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--trials", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--max-stars", type=int, default=1500)
+    ap.add_argument("--max-walkers", type=int, default=200, help="> 256 exercises the XCD-aware workgroup mapping")
+    ap.add_argument("--schedule", action="store_true", help="also randomise target_waves / tail_split per case")
     a = ap.parse_args()
     ctx = native.default_context()
     t0 = time.time()
@@ -39,8 +42,8 @@ def main():
                     continue
                 seed = a.seed * 1000003 + trial * 97 + model * 7 + int(free)
                 rng = np.random.default_rng(seed)
-                n = int(rng.integers(1, 1500))
-                w = int(rng.integers(1, 200))
+                n = int(rng.integers(1, a.max_stars))
+                w = int(rng.integers(1, a.max_walkers))
                 cat, params = random_case(rng, model, n=n, w=w)
                 kw = {}
                 if model == 1:
@@ -57,6 +60,9 @@ def main():
                     params = np.hstack([params[:, :head], cc, params[:, head:]])
                     centre = None
                 g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model, centre=centre, **kw)
+                if a.schedule:
+                    g.set_option("target_waves", int(rng.integers(1, 20000)))
+                    g.set_option("tail_split", int(rng.integers(0, 3)))
                 fast = g.loglike(params)
                 reruns += g.rerun_count
                 g.set_option("fast_path", 0)
