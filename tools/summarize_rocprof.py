@@ -3,6 +3,7 @@
 kept under profiles/.  Usage:
     python tools/summarize_rocprof.py stats <rocprof_dir> <out.txt>
     python tools/summarize_rocprof.py pmc <workload> <fetch_dir> <write_dir> <out.json> <kernel substring> [compulsory bytes]
+    python tools/summarize_rocprof.py sq <out.json> <kernel substring> <terms per launch> <pass_dir> [<pass_dir> ...]
 """
 import csv
 import glob
@@ -72,8 +73,45 @@ def pmc(workload, fetch_dir, write_dir, out, kernel_sub, compulsory=None):
     print(json.dumps(entry, indent=1))
 
 
+def sq(out, kernel_sub, terms, dirs):
+    """Mean SQ counter values per launch of the named kernel (tools/sq_counters.sh passes) + derived figures."""
+    mean, dur = {}, []
+    for d in dirs:
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+            if kernel_sub in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for k, v in acc.items():
+            mean[k] = sum(v) / len(v)
+    terms = float(terms)
+    n_cu = 256
+    cu_cycles = mean["SQ_BUSY_CU_CYCLES"]                 # busy cycles summed over the CUs
+    us = sum(dur) / len(dur) / 1e3
+    derived = {
+        "kernel_us_under_counters": us,
+        "shader_clock_GHz": cu_cycles / n_cu / (us * 1e3),
+        # SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD (the gfx94x VALUBusy formula: x 4 / SIMDs per CU / busy cycles)
+        "VALUBusy_percent": 100.0 * mean["SQ_ACTIVE_INST_VALU"] * 4 / 4 / cu_cycles,
+        "valu_instructions_per_term": mean["SQ_INSTS_VALU"] * 64 / terms,
+        "f64_fma_mul_add_trans_per_term": (mean["SQ_INSTS_VALU_FMA_F64"] + mean["SQ_INSTS_VALU_MUL_F64"] +
+                                           mean["SQ_INSTS_VALU_ADD_F64"] + mean["SQ_INSTS_VALU_TRANS_F64"]) * 64 / terms,
+        "int32_valu_per_term": mean["SQ_INSTS_VALU_INT32"] * 64 / terms,
+        "lds_instructions_per_term": mean["SQ_INSTS_LDS"] * 64 / terms,
+        "smem_instructions_per_wave": mean["SQ_INSTS_SMEM"] / mean["SQ_WAVES"],
+        "lds_active_fraction_of_cu_cycles": mean["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
+        "lds_bank_conflict_fraction_of_lds_active": mean["SQ_LDS_BANK_CONFLICT"] / mean["SQ_LDS_IDX_ACTIVE"],
+    }
+    data = {"kernel": kernel_sub, "terms_per_launch": terms, "counters_mean_per_launch": mean, "derived": derived,
+            "note": "rocprofv3 --pmc, three passes of 8 SQ counters (tools/sq_counters.sh); values are sums over the chip"}
+    json.dump(data, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps(derived, indent=1))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(*sys.argv[2:8])
