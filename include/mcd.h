@@ -172,8 +172,10 @@ double mcd_last_device_ms(const mcd_catalog* cat);
 /* Tuning / measurement switches, per catalogue.  Keys:
  *   "timing"        1: record HIP events around every enqueue (default 0); 2: additionally keep one
  *                      event pair per main-kernel launch for mcd_timing_collect
- *   "fast_path"     0: always use the plain per-term log/divide kernels (default 1: the fraction-tree /
- *                      log-product kernel is used whenever the per-call range guard allows it)
+ *   "fast_path"     0: always use the plain per-term log/divide kernels; 1 (default): the fast formulations
+ *                      (fraction tree / log-product / single-exp mixtures) are used whenever the per-call range
+ *                      guard allows, including the narrow-range variant of the fixed-background mixture;
+ *                      2: as 1 but never the narrow-range variant (testing aid)
  *   "zero_copy"     1 (default): on a single device mcd_loglike_batch lets the kernels read the parameter table
  *                      from / write the results to pinned mapped host memory instead of issuing H2D / D2H copies
  *   "target_waves"  number of waves the chunking aims for per device (default 12288)
@@ -190,6 +192,9 @@ int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_lau
  * f_back == 0 or density == 0 that lies > 37 sigma from the only remaining component.  Only the literal expression
  * reproduces the reference's value there; the re-evaluation is automatic and synchronous inside fetch / batch. */
 int64_t mcd_rerun_count(const mcd_catalog* cat);
+/* Kernel family the range guard chose for the batch staged last: 0 plain, 1 fast formulation, 2 narrow-range
+ * fixed-background variant (every pmember < 1, lnlike_bg >= -150: no per-star exponent bookkeeping); -1 before any call. */
+int mcd_last_fast_level(const mcd_catalog* cat);
 /* Launch geometry of the main kernel for the last call: workgroups, walker tile (walkers that
  * reuse one star record load), chunks per parameter set, bytes per star record. */
 int mcd_last_launch_info(const mcd_catalog* cat, int64_t* n_workgroups, int32_t* walker_tile,

@@ -51,6 +51,7 @@ SYMBOLS = {
     "mcd_last_device_ms": (ctypes.c_double, [ctypes.c_void_p]),
     "mcd_timing_collect": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_int64_p]),
     "mcd_rerun_count": (ctypes.c_int64, [ctypes.c_void_p]),
+    "mcd_last_fast_level": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "mcd_last_launch_info": (ctypes.c_int, [ctypes.c_void_p, _c_int64_p, ctypes.POINTER(ctypes.c_int32), _c_int64_p,
                                             ctypes.POINTER(ctypes.c_int32)]),
@@ -334,6 +335,11 @@ class Catalog(object):
     def rerun_count(self):
         """Batches re-evaluated with the plain kernels (denormal regime of the reference's log-sum-exp)."""
         return self.lib.mcd_rerun_count(self.handle)
+
+    @property
+    def fast_level(self):
+        """Kernel family of the batch staged last: 0 plain, 1 fast, 2 narrow-range fixed-background variant."""
+        return self.lib.mcd_last_fast_level(self.handle)
 
     def launch_info(self):
         wg, ch = ctypes.c_int64(), ctypes.c_int64()

@@ -107,7 +107,7 @@ struct WorkSet {
     double* m_out = nullptr;           // device view of h_out
     bool mapped = false;               // last staging used the zero-copy path: results land in h_out directly
     double launch_tag = 0.0;           // tag of the last fast-path launch (written to out[n_out] by a kernel that wants a re-run)
-    bool fast = false;
+    int fast = 0;                      // mcd::LaunchShape::fast level of the staged batch
     bool staged = false;
 };
 
@@ -148,7 +148,7 @@ struct mcd_catalog {
     // options
     bool timing = false;
     bool timing_all = false;           // keep an event pair for every launch (measurement harness)
-    bool allow_fast = true;
+    int allow_fast = 1;                // option "fast_path": 0 plain kernels only, 1 guard decides, 2 guard decides but never the narrow variant
     bool zero_copy = true;             // blocking call reads params / writes results through mapped pinned memory
     int tail_split = 1;                // guided chunk schedule (shorter chunks at the end of a launch)
     int64_t target_waves = 12288;
@@ -275,9 +275,10 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     return MCD_OK;
 }
 
-bool fast_guard(const mcd_catalog* cat, const double* params, int64_t n_rows) {
-    if (!cat->allow_fast) return false;
-    return mcd::fast_guard(cat->stats, cat->model, cat->free_centre, cat->precision != MCD_F64, cat->k, params, n_rows);
+int fast_level(const mcd_catalog* cat, const double* params, int64_t n_rows) {
+    if (!cat->allow_fast) return 0;
+    const int level = mcd::fast_level(cat->stats, cat->model, cat->free_centre, cat->precision != MCD_F64, cat->k, params, n_rows);
+    return cat->allow_fast == 2 && level > 1 ? 1 : level;
 }
 
 int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, bool zero_copy) {
@@ -289,7 +290,7 @@ int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* p
         return fail(MCD_ERR_INVALID, buf);
     }
     const int64_t n_rows = cat->n_psets * n_walkers;
-    const bool fast = fast_guard(cat, params, n_rows);
+    const int fast = fast_level(cat, params, n_rows);
     for (Shard& sh : cat->shards) {
         WorkSet* w = nullptr;
         int rc = build_workset(cat, sh, n_walkers, &w);
@@ -463,7 +464,7 @@ int fetch(mcd_catalog* cat, double* out) {
         // multi-rank job every rank must take the same decision (the all-reduce is collective): ranks agree through
         // the all-reduced flag below.
         ++cat->n_reruns;
-        for (Shard& sh : cat->shards) sh.work.at(W).fast = false;
+        for (Shard& sh : cat->shards) sh.work.at(W).fast = 0;
         rc = enqueue(cat);
         if (rc != MCD_OK) return rc;
         rc = fetch_once(cat, &rerun);
@@ -745,7 +746,7 @@ int per_star(mcd_catalog* cat, int32_t k, const double* params, int mode, double
         MCD_HIP(hipMalloc(&d_o, (size_t)sh.n * sizeof(double)));
         MCD_HIP(hipMemcpyAsync(d_p, params, k * sizeof(double), hipMemcpyHostToDevice, slot.stream));
         MCD_HIP(mcd::launch_prepare_walkers(slot.stream, d_p, 1, k, cat->model, cat->free_centre, cat->precision, d_w));
-        mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, false};
+        mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, 0};
         MCD_HIP(mcd::launch_per_star(slot.stream, shape, sh.records, sh.n, d_w, mode, d_o));
         MCD_HIP(hipMemcpyAsync(out + sh.star_begin, d_o, (size_t)sh.n * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
         MCD_HIP(hipStreamSynchronize(slot.stream));
@@ -826,7 +827,11 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         for (Shard& sh : cat->shards) sh.ring_used = 0;
         return MCD_OK;
     }
-    if (!std::strcmp(key, "fast_path")) { cat->allow_fast = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "fast_path")) {
+        if (value < 0 || value > 2) return fail(MCD_ERR_INVALID, "fast_path: 0 (plain), 1 (guarded, default) or 2 (guarded, no narrow variant)");
+        cat->allow_fast = (int)value;
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "zero_copy")) { cat->zero_copy = value != 0; return MCD_OK; }
     if (!std::strcmp(key, "tail_split") || !std::strcmp(key, "target_waves")) {
         const bool is_split = key[1] == 'a' && key[0] == 't' && key[2] == 'i';
@@ -864,6 +869,12 @@ int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_lau
 }
 
 int64_t mcd_rerun_count(const mcd_catalog* cat) { return cat ? cat->n_reruns : MCD_ERR_INVALID; }
+
+int mcd_last_fast_level(const mcd_catalog* cat) {
+    if (!cat || cat->cur_walkers <= 0 || cat->shards.empty()) return -1;
+    const auto it = cat->shards.front().work.find(cat->cur_walkers);
+    return it == cat->shards.front().work.end() ? -1 : it->second.fast;
+}
 
 double mcd_last_kernel_ms(const mcd_catalog* cat) { return cat ? cat->last_kernel_ms : -1.0; }
 double mcd_last_device_ms(const mcd_catalog* cat) { return cat ? cat->last_device_ms : -1.0; }

@@ -18,6 +18,8 @@ struct CatalogStats {
     double rho_min = 0, rho_max = 0;                // density range (BG_GAUSS / BG_FIXED_DENSITY)
     bool stats_finite = true;                       // v, verr all finite
     bool extras_ok = true;                          // background columns inside the fast-path ranges
+    double lnbg_min = 0;                            // BG_FIXED: smallest lnlike_bg, largest pmember (narrow variant)
+    double pmember_max = 0;
 };
 
 // Gathered once at upload from the host columns (runner.py:261: norm = verr*verr + sigma*sigma).
@@ -27,6 +29,7 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
     double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
     double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
     bool finite = true, ok = true;
+    double b_min = std::numeric_limits<double>::infinity(), pm_max = 0.0;
     for (int64_t i = 0; i < n; ++i) {
         const double e2 = verr[i] * verr[i];
         const double av = std::fabs(v[i]);
@@ -48,6 +51,8 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
             // vanishing prior there also makes the reference's log-sum-exp underflow (runner.py:282-284 gives -inf for
             // p == 0): the plain kernels reproduce that literally.
             if (lnbg[i] < -690.0 && !(pm >= 0x1p-700)) ok = false;
+            b_min = std::min(b_min, lnbg[i]);
+            pm_max = std::max(pm_max, pm);
         }
         if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) {
             const double rho = density[i];
@@ -60,6 +65,7 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
     if (n == 0) { e2_min = 0.0; r_min = 0.0; }
     st.e2_min = e2_min; st.e2_max = e2_max; st.v_abs_max = v_abs; st.stats_finite = finite;
     st.extras_ok = ok; st.rho_min = r_min; st.rho_max = r_max;
+    st.lnbg_min = b_min; st.pmember_max = pm_max;
     return st;
 }
 
@@ -70,7 +76,7 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
 // Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
 // expressions term by term.
 inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
-                       int64_t n_rows) {
+                       int64_t n_rows, double* n_min_out = nullptr) {
     if (!st.stats_finite || n_rows == 0) return false;
     if (f32 && bg_kind(model) != BG_NONE) return false;      // f32 mixtures use the plain kernels
     const bool prof = is_profile(model);
@@ -113,6 +119,7 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
     if (!(d_max <= std::ldexp(1.0, 58))) return false;
     // sigma_los of the profile models decays to 0 at large r: only verr^2 bounds the variance from below
     const double n_min = st.e2_min + (prof ? 0.0 : s2_min), n_max = st.e2_max + s2_max;
+    if (n_min_out) *n_min_out = n_min;
     if (prof && !(len_min >= std::ldexp(1.0, -100) && len_max <= std::ldexp(1.0, 100))) return false;   // a, r_peak > 0
     if (bg == BG_NONE) {
         if (f32)      // 4-star tree in f32: DEN <= 2^60, NUM <= 2^77
@@ -132,6 +139,17 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
     if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY)
         return f_min >= 0.0 && (st.rho_min + f_min >= std::ldexp(1.0, -100)) && (st.rho_max + f_max <= std::ldexp(1.0, 100));
     return true;
+}
+
+// Launch level for mcd::LaunchShape::fast: 0 plain kernels, 1 fast formulation, 2 narrow-range BGFIXED variant
+// (BgFixedAcc::add<.., NARROW>): additionally pmember < 1 for every star (so every mixture value y >= 1 - p >= 2^-53),
+// lnlike_bg >= -150 and norm >= 2^-60 (so y <= 1 + 2 norm^-1/2 e^150 < 2^250): four raw factors fit between rescales.
+inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
+                      int64_t n_rows) {
+    double n_min = 0.0;
+    if (!fast_guard(st, model, free_centre, f32, k, params, n_rows, &n_min)) return 0;
+    if (model == MODEL_BGFIXED && !f32 && st.lnbg_min >= -150.0 && st.pmember_max < 1.0 && n_min >= 0x1p-60) return 2;
+    return 1;
 }
 
 }  // namespace mcd

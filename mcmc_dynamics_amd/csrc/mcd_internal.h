@@ -19,7 +19,7 @@ struct LaunchShape {
     int model;        // mcd::Model
     bool free_centre;
     int precision;    // mcd_precision
-    bool fast;        // product/fraction-tree path allowed (range guard passed)
+    int fast;         // 0 plain; 1 product/fraction-tree path (range guard passed); 2 narrow-range BGFIXED variant
     int uniform_len = 0;     // > 0: chunk c covers records [c * len, min((c + 1) * len, n_records)) of parameter set 0
     int64_t n_records = 0;
     double* rerun_flag = nullptr;   // device word the fast mixture kernels set to `launch_tag` in the denormal regime

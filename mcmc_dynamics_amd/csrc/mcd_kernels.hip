@@ -117,7 +117,7 @@ __device__ const double kExpTabSqrt2Device[kExpTabSize] = {MCD_EXP_TABLE_SQRT2_V
 
 // ------------------------------------------------------------------------------------------------
 // main kernel (the per-chunk arithmetic lives in mcd_math.h: chunk_loglike)
-template <int MODEL, bool FREE, class T, class A, bool FAST>
+template <int MODEL, bool FREE, class T, class A, int FAST>
 __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ recs,
                                                           const Chunk* __restrict__ chunks,
                                                           const T* __restrict__ wpar,
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void per_star_kernel(const T* __restrict__ 
     out[i] = (double)(ec / (ec + eb));
 }
 
-template <int MODEL, bool FREE, class T, class A, bool FAST>
+template <int MODEL, bool FREE, class T, class A, int FAST>
 hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, int64_t n_chunks, const void* wpar,
                       double* partials, int64_t n_walkers, int uniform_len, int64_t n_records, double* rerun_flag,
                       double launch_tag) {
@@ -274,20 +274,25 @@ hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* re
     const double launch_tag = sh.launch_tag;
     switch (sh.precision) {
         case 0:
+            if constexpr (MODEL == MODEL_BGFIXED) {
+                if (sh.fast == 2)
+                    return launch_one<MODEL, FREE, double, double, 2>(s, records, chunks, n_chunks, wpar, partials,
+                                                                      n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+            }
             if (sh.fast)
-                return launch_one<MODEL, FREE, double, double, true>(s, records, chunks, n_chunks, wpar, partials,
-                                                                     n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
-            return launch_one<MODEL, FREE, double, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+                return launch_one<MODEL, FREE, double, double, 1>(s, records, chunks, n_chunks, wpar, partials,
+                                                                  n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+            return launch_one<MODEL, FREE, double, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
         case 1:
             if (sh.fast && bg_kind(MODEL) == BG_NONE)
-                return launch_one<MODEL, FREE, float, float, bg_kind(MODEL) == BG_NONE>(s, records, chunks, n_chunks, wpar,
+                return launch_one<MODEL, FREE, float, float, bg_kind(MODEL) == BG_NONE ? 1 : 0>(s, records, chunks, n_chunks, wpar,
                                                                                        partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
-            return launch_one<MODEL, FREE, float, float, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+            return launch_one<MODEL, FREE, float, float, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
         case 2:
             if (sh.fast && bg_kind(MODEL) == BG_NONE)
-                return launch_one<MODEL, FREE, float, double, bg_kind(MODEL) == BG_NONE>(s, records, chunks, n_chunks, wpar,
+                return launch_one<MODEL, FREE, float, double, bg_kind(MODEL) == BG_NONE ? 1 : 0>(s, records, chunks, n_chunks, wpar,
                                                                                         partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
-            return launch_one<MODEL, FREE, float, double, false>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+            return launch_one<MODEL, FREE, float, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
     }
     return hipErrorInvalidValue;
 }

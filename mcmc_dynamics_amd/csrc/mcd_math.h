@@ -453,7 +453,11 @@ struct BgFixedAcc {
     // HALVED: the caller passes 2 n instead of n and the table sqrt(2) 2^(j/256) (MCD_EXP_TABLE_SQRT2_VALUES):
     //   gh = (2 n)^(-1/2) = g / sqrt(2),  -(d gh)^2 = -1/2 d^2 g^2,  p gh (sqrt(2) T[j]) e^r = p g T[j] e^r,
     // which drops the multiplication by -1/2 (2 n = 2 verr^2 + 2 sigma^2 is formed by one FMA, like n by one add).
-    template <bool UNIFORM_OMP = true, bool HALVED = false>
+    // NARROW (chosen per call by the host guard, mcd_guard.h: fast_level): every y_i is known to lie in [2^-53, 2^250]
+    // -- pmember < 1 everywhere, so y >= 1 - p >= 2^-53; lnL_bg >= -150 and norm >= 2^-60, so y <= 1 + 2 g e^{150} --
+    // hence four raw factors can be multiplied between two rescales without the per-star mantissa/exponent split,
+    // without the k > 1000 exponent carry and without the denormal-regime tracking (7 VALU instructions per term less).
+    template <bool UNIFORM_OMP = true, bool HALVED = false, bool NARROW = false>
     MCD_HD void add(double d, double n, double p, double omp, double nbp, const double* __restrict__ exptab) {
         const double g = rsqrt_nr(n);
         const double dg = d * g;
@@ -462,6 +466,11 @@ struct BgFixedAcc {
         const double u = fmax_raw(HALVED ? fnma_sgpr_addend(dg, dg, nbp) : fma_sgpr_addend(-0.5 * dg, dg, nbp), -1100.0);
         int k;
         const double er = exp_tab(u, k, exptab);
+        if constexpr (NARROW) {
+            const double y = UNIFORM_OMP ? fma_sgpr_addend(p * g, ldexp_(er, k), omp) : fma_(p * g, ldexp_(er, k), omp);
+            l.mul(y);
+            return;
+        }
         // y = (1 - p) + p g e^r 2^k.  k > 1000 (cluster likelihood e^693 times the background's) is carried in the
         // integer part of the product: there the (1 - p) term is below 2^-900 of y and drops out exactly as in f64.
         // k < -1074 underflows inside ldexp; with p == 1 exactly that gives y = 0 and lnL = -inf, which is also what
@@ -611,7 +620,9 @@ MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T&
 // for MODEL_BGFIXED it is the sqrt(2)-scaled table (exp_table_is_sqrt2_scaled).
 MCD_HD constexpr bool exp_table_is_sqrt2_scaled(int model) { return model == MODEL_BGFIXED; }
 
-template <int MODEL, bool FREE, class T, class A, bool FAST>
+// FAST: 0 = plain (the reference's expressions term by term), 1 = fast formulation, 2 = fast formulation with the
+// narrow-range product of BgFixedAcc::add (MODEL_BGFIXED only; otherwise the same as 1).
+template <int MODEL, bool FREE, class T, class A, int FAST>
 MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w, bool& denormal,
                             const double* __restrict__ exptab) {
     constexpr int ND = record_doubles(MODEL, FREE);
@@ -692,6 +703,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         // MODEL_BGFIXED has norm = verr^2 + sigma^2 (constant.py:52-74): the accumulator takes 2 norm (HALVED form) and
         // `exptab` is then the sqrt(2)-scaled table; star_d_n's own norm is dead code there.
         constexpr bool HALVED = MODEL == MODEL_BGFIXED;
+        constexpr bool NARROW = FAST == 2 && MODEL == MODEL_BGFIXED;
         const double s2x2 = (double)w.s2 + (double)w.s2;
         BgFixedAcc acc;
         acc.init();
@@ -703,7 +715,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
                 if constexpr (HALVED) n = fma_(2.0, rr[1], s2x2);
-                acc.add<true, HALVED>(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3], exptab);
+                acc.add<true, HALVED, NARROW>(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3], exptab);
             }
             acc.rescale();
         }
@@ -711,7 +723,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
             if constexpr (HALVED) n = fma_(2.0, r[1], s2x2);
-            acc.add<true, HALVED>(d, n, r[XB + 1], r[XB + 2], r[XB + 3], exptab);
+            acc.add<true, HALVED, NARROW>(d, n, r[XB + 1], r[XB + 2], r[XB + 3], exptab);
             acc.rescale();
         }
         result = acc.finish();

@@ -12,7 +12,7 @@ using namespace mcd;
 static const double kExpTabHost[kExpTabSize] = {MCD_EXP_TABLE_VALUES};
 static const double kExpTabSqrt2Host[kExpTabSize] = {MCD_EXP_TABLE_SQRT2_VALUES};
 
-template <int MODEL, bool FREE, bool FAST>
+template <int MODEL, bool FREE, int FAST>
 static void run(int64_t n, const double* recs, const double* wpar, int64_t W, int64_t chunk_len, double* out) {
     constexpr int ND = record_doubles(MODEL, FREE);
     for (int64_t w = 0; w < W; ++w) {
@@ -31,7 +31,7 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
             for (int64_t s = 0; s < n; s += chunk_len) {
                 const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
                 bool dummy;
-                total += chunk_loglike<MODEL, FREE, double, double, false>(recs + s * ND, count, c, dummy, kExpTabHost);
+                total += chunk_loglike<MODEL, FREE, double, double, 0>(recs + s * ND, count, c, dummy, kExpTabHost);
             }
             out[w] = total;
             continue;
@@ -69,9 +69,14 @@ extern "C" int emul_kd() { return KD; }
 #define FOR_ALL(M) CASE(M, false, false) CASE(M, false, true) CASE(M, true, false) CASE(M, true, true)
 extern "C" int emul_loglike(int model, int free_centre, int fast, int64_t n, const double* recs, const double* wpar,
                             int64_t W, int64_t chunk_len, double* out) {
-#define CASE(M, F, X) if (model == M && (free_centre != 0) == F && (fast != 0) == X) { run<M, F, X>(n, recs, wpar, W, chunk_len, out); return 0; }
+#define CASE(M, F, X) if (model == M && (free_centre != 0) == F && (fast != 0) == X && fast != 2) { run<M, F, X ? 1 : 0>(n, recs, wpar, W, chunk_len, out); return 0; }
     FOR_ALL(0) FOR_ALL(1) FOR_ALL(2) FOR_ALL(3) FOR_ALL(4) FOR_ALL(5)
 #undef CASE
+    if (model == 1 && fast == 2) {            // narrow-range BGFIXED variant
+        if (free_centre) run<1, true, 2>(n, recs, wpar, W, chunk_len, out);
+        else run<1, false, 2>(n, recs, wpar, W, chunk_len, out);
+        return 0;
+    }
     return -1;
 }
 
@@ -88,7 +93,7 @@ extern "C" int emul_fast_guard(int model, int free_centre, int f32, int64_t n, c
                                const double* lnbg, const double* pmember, const double* density, int k,
                                const double* params, int64_t n_rows) {
     const CatalogStats st = compute_stats(n, v, verr, lnbg, pmember, density, bg_kind(model));
-    return fast_guard(st, model, free_centre != 0, f32 != 0, k, params, n_rows) ? 1 : 0;
+    return fast_level(st, model, free_centre != 0, f32 != 0, k, params, n_rows);
 }
 
 // background.SingleStars: the device's per-lane slice arithmetic (KdeLane) and the slice combination of

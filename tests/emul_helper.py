@@ -125,12 +125,17 @@ def per_star(cat, params_row, model, centre, mode):
 
 
 def fast_guard(cat, params, model, centre, f32=False):
-    """The library's per-call range guard (csrc/mcd_guard.h) for this catalogue and C-ABI parameter table."""
+    """The library's per-call range guard (csrc/mcd_guard.h): is a fast formulation admitted?"""
+    return fast_level(cat, params, model, centre, f32) > 0
+
+
+def fast_level(cat, params, model, centre, f32=False):
+    """Launch level the library would choose (csrc/mcd_guard.h: fast_level): 0 plain, 1 fast, 2 narrow-range BGFIXED."""
     lib().emul_fast_guard.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 5 + \
         [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
     cols = [np.ascontiguousarray(cat[k], dtype=np.float64) if k in cat else None
             for k in ("v", "verr", "lnlike_bg", "pmember", "density")]
     params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
     ptr = [c.ctypes.data if c is not None else None for c in cols]
-    return bool(lib().emul_fast_guard(model, int(centre is None), int(f32), len(cat["v"]), *ptr, params.shape[1],
-                                      params.ctypes.data, params.shape[0]))
+    return int(lib().emul_fast_guard(model, int(centre is None), int(f32), len(cat["v"]), *ptr, params.shape[1],
+                                     params.ctypes.data, params.shape[0]))

@@ -50,14 +50,22 @@ def test_constant_free_centre_golden(native, ctx, fast):
 
 
 @pytest.mark.parametrize("which", ["fixed", "free"])
-def test_fixed_gaussian_background_golden(native, ctx, which):
+@pytest.mark.parametrize("fast_path,level", [(1, 2), (2, 1), (0, 0)])
+def test_fixed_gaussian_background_golden(native, ctx, which, fast_path, level):
+    """ConstantFit + background.Gaussian against lnprob of the reference, through all three kernel families: the
+    narrow-range variant (what the guard picks for this catalogue: every pmember < 1, lnL_bg > -150), the general fast
+    formulation and the plain kernels."""
     g = load_golden("constant_bg_gaussian_" + which)
     centre = (float(g["ra_center"]), float(g["dec_center"])) if which == "fixed" else None
     cat = native.Catalog(ctx, g["ra"], g["dec"], g["v"], g["verr"], model=native.MODEL_CONST_BGFIXED, centre=centre,
                          lnlike_bg=g["lnlike_background"], pmember=g["pmember"])
-    got = cat.loglike(g["values"])
+    cat.set_option("fast_path", fast_path)
     want, ok = _likelihood_part(g)
-    assert rel_err(got[ok], want[ok]) < RTOL
+    ok &= g["values"][:, 1] > 0                       # sigma = 0 rows: the guard sends the whole batch to the plain kernels
+    got = cat.loglike(g["values"][ok])
+    assert cat.fast_level == level
+    assert rel_err(got, want[ok]) < RTOL
+    assert rel_err(cat.loglike(g["values"])[_likelihood_part(g)[1]], want[_likelihood_part(g)[1]]) < RTOL
 
 
 @pytest.mark.parametrize("which", ["fixed", "free"])

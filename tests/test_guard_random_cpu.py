@@ -50,7 +50,8 @@ def test_guarded_fast_path_agrees_with_plain_path(model):
             refused += 1
             continue
         admitted += 1
-        fast = emul.loglike(cat, params, model, CENTRE, 1, chunk_len=64)
+        level = emul.fast_level(cat, params, model, CENTRE)        # 2: the narrow-range BGFIXED variant is what would run
+        fast = emul.loglike(cat, params, model, CENTRE, level, chunk_len=64)
         both = np.isfinite(plain) & np.isfinite(fast)
         assert np.array_equal(np.isfinite(plain), np.isfinite(fast)), (trial, plain, fast)
         assert rel_err(fast[both], plain[both]) < 1e-11, (trial, plain, fast)

@@ -162,3 +162,56 @@ def test_underflow_window_between_the_two_formulations(seed, model):
     assert np.array_equal(np.isfinite(plain), np.isfinite(fast))
     ok = np.isfinite(plain)
     assert rel_err(fast[ok], plain[ok]) < 1e-11
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+@pytest.mark.parametrize("chunk_len", [64, 248, 100000])
+def test_narrow_range_bgfixed_variant_matches_reference(which, chunk_len):
+    """The narrow-range variant of the fixed-background fast path (raw product of four mixture values between rescales,
+    no exponent carry, no denormal tracking; chosen by mcd_guard.h: fast_level when pmember < 1 everywhere, lnL_bg >= -150
+    and norm >= 2^-60) against lnprob of the reference (runner.py:272-286)."""
+    g = load_golden("constant_bg_gaussian_" + which)
+    free = which == "free"
+    cat = {k: g[k] for k in ("ra", "dec", "v", "verr", "pmember")}
+    cat["lnlike_bg"] = g["lnlike_background"]
+    centre = None if free else (float(g["ra_center"]), float(g["dec_center"]))
+    ok = np.isfinite(g["lnprob"]) & (g["values"][:, 1] > 0)
+    values = emul.abi_columns(g["names"], g["values"], 1, free)[ok]
+    assert cat["pmember"].max() < 1.0 and cat["lnlike_bg"].min() > -150.0
+    assert emul.fast_level(cat, values, 1, centre) == 2
+    got = emul.loglike(cat, values, 1, centre, 2, chunk_len)
+    assert rel_err(got, g["lnprob"][ok]) < RTOL
+
+
+def test_narrow_range_level_conditions():
+    """fast_level drops from 2 to 1 as soon as one condition of the narrow variant fails: a certain member
+    (pmember == 1: the mixture value can underflow) or a background likelihood below e^-150 (the value can exceed
+    2^250); and the narrow variant agrees with the wide one at the edges of its domain."""
+    g = load_golden("constant_bg_gaussian_fixed")
+    centre = (float(g["ra_center"]), float(g["dec_center"]))
+    rows = g["values"][np.isfinite(g["lnprior"]) & (g["values"][:, 1] > 0)]
+    base = {k: g[k].copy() for k in ("ra", "dec", "v", "verr", "pmember")}
+    base["lnlike_bg"] = g["lnlike_background"].copy()
+    assert emul.fast_level(base, rows, 1, centre) == 2
+    cat = dict(base, pmember=base["pmember"].copy())
+    cat["pmember"][5] = 1.0
+    assert emul.fast_level(cat, rows, 1, centre) == 1
+    cat = dict(base, lnlike_bg=base["lnlike_bg"].copy())
+    cat["lnlike_bg"][5] = -151.0
+    assert emul.fast_level(cat, rows, 1, centre) == 1
+    # (the third condition, norm >= 2^-60, only binds for velocity scales below 1e-9 km/s: the level-1 guard
+    #  |v - v_los|^2 <= 1.6e9 norm is stricter for anything larger)
+    assert emul.fast_level(base, rows, 0, centre) == 1              # other models have no narrow variant
+    # edges of the domain: lnL_bg = -150 on a star the cluster model loves (largest y), pmember = 1 - 2^-53 (smallest y)
+    # on 80-sigma outliers, four of them in a row so that they share one rescale group
+    edge = {k: v.copy() for k, v in base.items()}
+    edge["lnlike_bg"][:4] = -150.0
+    edge["v"][:4] = rows[0, 0]
+    edge["pmember"][8:12] = 1.0 - 2.0 ** -53
+    edge["v"][8:12] = 800.0
+    edge["verr"][:12] = 1e-3
+    assert emul.fast_level(edge, rows, 1, centre) == 2
+    narrow = emul.loglike(edge, rows, 1, centre, 2, 64)
+    plain = emul.loglike(edge, rows, 1, centre, 0, 64)
+    assert np.all(np.isfinite(plain)) and rel_err(narrow, plain) < RTOL
+    assert rel_err(emul.loglike(edge, rows, 1, centre, 1, 64), plain) < RTOL
