@@ -76,7 +76,7 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
 // Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
 // expressions term by term.
 inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
-                       int64_t n_rows, double* n_min_out = nullptr) {
+                       int64_t n_rows, double* n_min_out = nullptr, double* d_max_out = nullptr) {
     if (!st.stats_finite || n_rows == 0) return false;
     if (f32 && bg_kind(model) != BG_NONE) return false;      // f32 mixtures use the plain kernels
     const bool prof = is_profile(model);
@@ -120,6 +120,7 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
     // sigma_los of the profile models decays to 0 at large r: only verr^2 bounds the variance from below
     const double n_min = st.e2_min + (prof ? 0.0 : s2_min), n_max = st.e2_max + s2_max;
     if (n_min_out) *n_min_out = n_min;
+    if (d_max_out) *d_max_out = d_max;
     if (prof && !(len_min >= std::ldexp(1.0, -100) && len_max <= std::ldexp(1.0, 100))) return false;   // a, r_peak > 0
     if (bg == BG_NONE) {
         if (f32)      // 4-star tree in f32: DEN <= 2^60, NUM <= 2^77
@@ -143,12 +144,16 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
 
 // Launch level for mcd::LaunchShape::fast: 0 plain kernels, 1 fast formulation, 2 narrow-range BGFIXED variant
 // (BgFixedAcc::add<.., NARROW>): additionally pmember < 1 for every star (so every mixture value y >= 1 - p >= 2^-53),
-// lnlike_bg >= -150 and norm >= 2^-60 (so y <= 1 + 2 norm^-1/2 e^150 < 2^250): four raw factors fit between rescales.
+// lnlike_bg >= -150 and norm >= 2^-60 (so y <= 1 + 2 norm^-1/2 e^150 < 2^250): four raw factors fit between rescales;
+// and |v - v_los|^2 <= 1e7 norm.
 inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
                       int64_t n_rows) {
-    double n_min = 0.0;
-    if (!fast_guard(st, model, free_centre, f32, k, params, n_rows, &n_min)) return 0;
-    if (model == MODEL_BGFIXED && !f32 && st.lnbg_min >= -150.0 && st.pmember_max < 1.0 && n_min >= 0x1p-60) return 2;
+    double n_min = 0.0, d_max = 0.0;
+    if (!fast_guard(st, model, free_centre, f32, k, params, n_rows, &n_min, &d_max)) return 0;
+    // (d_max^2 <= 1e7 n_min: the exponent argument stays above -5e6, inside the int range of exp_tab without a clamp)
+    if (model == MODEL_BGFIXED && !f32 && st.lnbg_min >= -150.0 && st.pmember_max < 1.0 && n_min >= 0x1p-60 &&
+        d_max * d_max <= 1.0e7 * n_min)
+        return 2;
     return 1;
 }
 

@@ -391,6 +391,7 @@ MCD_HD double rcp_nr(double x) {
 // k comes out of the low word of u * (256 / ln 2) + 1.5 * 2^52 (round-to-nearest-even), so no v_rndne / v_cvt.
 // Requires |u| < 2^21 (callers clamp or are bounded by the host guard).  About 5 f64 VALU fewer than a table-free
 // degree-11 polynomial on |r| <= ln 2 / 2 (measured: BGFIXED 327 -> see DESIGN.md section 3.2).
+template <bool TWO_STEP = true>
 MCD_HD double exp_tab(double u, int& e_out, const double* __restrict__ tab) {
     constexpr double kMagic = 6755399441055744.0;            // 1.5 * 2^52
     const double shifted = fma_(u, kExpTabInvStep, kMagic);
@@ -398,8 +399,15 @@ MCD_HD double exp_tab(double u, int& e_out, const double* __restrict__ tab) {
     uint64_t bits;
     std::memcpy(&bits, &shifted, sizeof bits);
     const int k = (int)(uint32_t)bits;
-    double r = fma_(-kf, kExpTabStepHi, u);
-    r = fma_(-kf, kExpTabStepLo, r);
+    double r;
+    if constexpr (TWO_STEP) {
+        r = fma_(-kf, kExpTabStepHi, u);
+        r = fma_(-kf, kExpTabStepLo, r);
+    } else {
+        // one-constant reduction: ln 2 / 256 rounded to f64 is off by < 2.2e-19, so r is off by < 2.2e-19 |k|, i.e. a
+        // relative error of 8e-17 |u| in e^u -- for callers whose |u| is small wherever e^u matters
+        r = fma_(-kf, kExpTabStepHi + kExpTabStepLo, u);
+    }
     double p = fma_(r, 1.0 / 24.0, 1.0 / 6.0);
     p = fma_(p, r, 0.5);
     p = fma_(p, r, 1.0);
@@ -463,7 +471,9 @@ struct BgFixedAcc {
         const double dg = d * g;
         // u <= 1e5 by the host guard (|lnL_bg| <= 1e5); below -1100 e^u is an exact 0 in f64 (as in the reference),
         // and the clamp keeps 256 u / ln 2 inside the int range of exp_tab.
-        const double u = fmax_raw(HALVED ? fnma_sgpr_addend(dg, dg, nbp) : fma_sgpr_addend(-0.5 * dg, dg, nbp), -1100.0);
+        // (NARROW: the guard bounds |v - v_los|^2 / norm by 1e7, so u > -5e6 needs no clamp)
+        const double u0 = HALVED ? fnma_sgpr_addend(dg, dg, nbp) : fma_sgpr_addend(-0.5 * dg, dg, nbp);
+        const double u = NARROW ? u0 : fmax_raw(u0, -1100.0);
         int k;
         const double er = exp_tab(u, k, exptab);
         if constexpr (NARROW) {
