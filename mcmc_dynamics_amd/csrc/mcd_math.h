@@ -475,7 +475,7 @@ struct BgFixedAcc {
         const double u0 = HALVED ? fnma_sgpr_addend(dg, dg, nbp) : fma_sgpr_addend(-0.5 * dg, dg, nbp);
         const double u = NARROW ? u0 : fmax_raw(u0, -1100.0);
         int k;
-        const double er = exp_tab(u, k, exptab);
+        const double er = exp_tab<!NARROW>(u, k, exptab);
         if constexpr (NARROW) {
             const double y = UNIFORM_OMP ? fma_sgpr_addend(p * g, ldexp_(er, k), omp) : fma_(p * g, ldexp_(er, k), omp);
             l.mul(y);
