@@ -14,10 +14,10 @@ from collections import defaultdict
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit("no *{0} under {1}".format(suffix, d))
-    return hits[-1]
+    return hits[-1]                                        # the newest run when a directory was reused
 
 
 def stats(d, out):
