@@ -85,7 +85,8 @@ int load_rccl() {
 
 struct DeviceSlot {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // kernels, copies
+    hipStream_t comm_stream = nullptr;   // the per-step all-reduce, so that it overlaps the next step's kernels
     ncclComm_t comm = nullptr;
 };
 
@@ -100,7 +101,13 @@ struct WorkSet {
     double* d_params = nullptr;        // [n_psets][W][K]
     void* d_wpar = nullptr;            // [n_psets][W][KD]
     double* d_partials = nullptr;      // [W][n_chunks]
-    double* d_out = nullptr;           // [n_psets][W]
+    double* d_out = nullptr;           // [n_psets][W] (+ flag word)
+    double* d_out2 = nullptr;          // second result buffer: collective mode alternates between the two, so that the
+                                       // all-reduce of step i (comm stream) overlaps the kernels of step i + 1
+    int buf = 0;                       // buffer the last enqueue wrote (always 0 without a collective)
+    hipEvent_t ev_reduced[2] = {nullptr, nullptr};   // reduce kernel done, buffer b ready for the all-reduce
+    hipEvent_t ev_comm[2] = {nullptr, nullptr};      // all-reduce of buffer b done
+    bool comm_pending[2] = {false, false};
     double* h_params = nullptr;        // pinned + mapped
     double* h_out = nullptr;           // pinned + mapped
     double* m_params = nullptr;        // device view of h_params (zero-copy path of the blocking call)
@@ -180,6 +187,11 @@ void free_workset(WorkSet& w) {
     if (w.d_wpar) (void)hipFree(w.d_wpar);
     if (w.d_partials) (void)hipFree(w.d_partials);
     if (w.d_out) (void)hipFree(w.d_out);
+    if (w.d_out2) (void)hipFree(w.d_out2);
+    for (int b = 0; b < 2; ++b) {
+        if (w.ev_reduced[b]) (void)hipEventDestroy(w.ev_reduced[b]);
+        if (w.ev_comm[b]) (void)hipEventDestroy(w.ev_comm[b]);
+    }
     if (w.h_params) (void)hipHostFree(w.h_params);
     if (w.h_out) (void)hipHostFree(w.h_out);
     w = WorkSet();
@@ -255,6 +267,12 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
         if ((e = hipMalloc(&w.d_partials, std::max<size_t>(1, (size_t)n_walkers * w.n_chunks) * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_out, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;   // + re-run flag word
         if ((e = hipMemset(w.d_out, 0, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&w.d_out2, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMemset(w.d_out2, 0, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
+        for (int b = 0; b < 2; ++b) {
+            if ((e = hipEventCreateWithFlags(&w.ev_reduced[b], hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&w.ev_comm[b], hipEventDisableTiming)) != hipSuccess) return e;
+        }
         if ((e = hipHostMalloc(&w.h_params, (size_t)n_out * cat->k * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
         if ((e = hipHostMalloc(&w.h_out, (size_t)(n_out + 1) * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
         std::memset(w.h_out, 0, (size_t)(n_out + 1) * sizeof(double));
@@ -335,7 +353,20 @@ int enqueue(mcd_catalog* cat) {
         // devices: the word is zeroed, kernels write 1, and the word rides along in the all-reduce (count n_out + 1),
         // so that every rank sees the same sum and takes the same decision.
         const bool coll = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
-        shape.rerun_flag = (w.mapped ? w.m_out : w.d_out) + n_out;
+        double* out_buf = w.mapped ? w.m_out : w.d_out;
+        if (coll) {
+            // alternate result buffers; this step may only overwrite its buffer once the all-reduce that last used it
+            // (two steps ago, on the comm stream) has finished
+            w.buf ^= 1;
+            out_buf = w.buf ? w.d_out2 : w.d_out;
+            if (w.comm_pending[w.buf]) {
+                MCD_HIP(hipStreamWaitEvent(slot.stream, w.ev_comm[w.buf], 0));
+                w.comm_pending[w.buf] = false;
+            }
+        } else {
+            w.buf = 0;
+        }
+        shape.rerun_flag = out_buf + n_out;
         if (coll) {
             w.launch_tag = 1.0;
             MCD_HIP(hipMemsetAsync(shape.rerun_flag, 0, sizeof(double), slot.stream));
@@ -365,7 +396,8 @@ int enqueue(mcd_catalog* cat) {
         const double* pset_const =
             (w.fast && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
         MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, w.n_chunks,
-                                   w.max_chunks_per_pset, W, pset_const, w.mapped ? w.m_out : w.d_out));
+                                   w.max_chunks_per_pset, W, pset_const, out_buf));
+        if (coll) MCD_HIP(hipEventRecord(w.ev_reduced[w.buf], slot.stream));
     }
     // sum the per-device / per-rank partial log-likelihoods: one all-reduce of n_out doubles
     const bool collective = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
@@ -375,9 +407,18 @@ int enqueue(mcd_catalog* cat) {
             WorkSet& w = sh.work.at(W);
             const DeviceSlot& slot = ctx->slots[sh.slot];
             MCD_HIP(hipSetDevice(slot.device));
-            MCD_NCCL(g_rccl.AllReduce(w.d_out, w.d_out, (size_t)n_out + 1, ncclDouble, ncclSum, slot.comm, slot.stream));
+            double* buf = w.buf ? w.d_out2 : w.d_out;
+            MCD_HIP(hipStreamWaitEvent(slot.comm_stream, w.ev_reduced[w.buf], 0));
+            MCD_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n_out + 1, ncclDouble, ncclSum, slot.comm, slot.comm_stream));
         }
         if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
+        for (Shard& sh : cat->shards) {
+            WorkSet& w = sh.work.at(W);
+            const DeviceSlot& slot = ctx->slots[sh.slot];
+            MCD_HIP(hipSetDevice(slot.device));
+            MCD_HIP(hipEventRecord(w.ev_comm[w.buf], slot.comm_stream));
+            w.comm_pending[w.buf] = true;
+        }
     }
     if (cat->timing) {
         if (!cat->timing_all) {
@@ -404,6 +445,7 @@ int sync_all(mcd_catalog* cat) {
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         MCD_HIP(hipStreamSynchronize(slot.stream));
+        MCD_HIP(hipStreamSynchronize(slot.comm_stream));
     }
     if (cat->timing && cat->timing_pending) {
         Shard& sh = cat->shards[0];
@@ -431,8 +473,10 @@ int fetch_once(mcd_catalog* cat, bool* rerun) {
         MCD_HIP(hipSetDevice(slot.device));
         if (!w.mapped) {
             const bool first = &sh == &cat->shards[0];
+            const double* res = w.buf ? w.d_out2 : w.d_out;
+            if (w.comm_pending[w.buf]) MCD_HIP(hipStreamWaitEvent(slot.stream, w.ev_comm[w.buf], 0));
             double* dst = first ? w.h_out : w.h_out + n_out;
-            const double* src = first ? w.d_out : w.d_out + n_out;
+            const double* src = first ? res : res + n_out;
             MCD_HIP(hipMemcpyAsync(dst, src, (size_t)(first ? n_out + 1 : 1) * sizeof(double), hipMemcpyDeviceToHost,
                                    slot.stream));
         }
@@ -482,6 +526,7 @@ int make_slot(int device, DeviceSlot* slot) {
         return fail(MCD_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     slot->device = device;
     MCD_HIP(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
+    MCD_HIP(hipStreamCreateWithFlags(&slot->comm_stream, hipStreamNonBlocking));
     return MCD_OK;
 }
 
@@ -566,6 +611,7 @@ int mcd_ctx_destroy(mcd_ctx* ctx) {
         (void)hipSetDevice(s.device);
         if (s.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s.comm);
         if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.comm_stream) (void)hipStreamDestroy(s.comm_stream);
     }
     delete ctx;
     return MCD_OK;
@@ -692,6 +738,7 @@ int mcd_catalog_destroy(mcd_catalog* cat) {
     for (Shard& sh : cat->shards) {
         (void)hipSetDevice(cat->ctx->slots[sh.slot].device);
         (void)hipStreamSynchronize(cat->ctx->slots[sh.slot].stream);
+        (void)hipStreamSynchronize(cat->ctx->slots[sh.slot].comm_stream);
         for (auto& kv : sh.work) free_workset(kv.second);
         if (sh.records) (void)hipFree(sh.records);
         if (sh.d_pset_const) (void)hipFree(sh.d_pset_const);

@@ -302,7 +302,38 @@ def test_rccl_call_path_on_one_rank(native):
     cat = native.Catalog(ctx1, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
     for _ in range(3):
         assert np.array_equal(cat.loglike(pos), ref)
+    # Pipelined use: the all-reduce of step i runs on the communication stream while step i + 1 computes, results
+    # alternate between two buffers.  Different walker tables per step, so that a stale or half-reduced buffer shows.
+    plain = native.Catalog(native.default_context(), c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST,
+                           centre=centre)
+    rng = np.random.default_rng(5)
+    for depth in (1, 2, 3, 7):
+        tables = [pos * (1.0 + 0.01 * rng.normal(size=pos.shape)) for _ in range(depth)]
+        for t in tables[:-1]:                       # results of these steps are overwritten, never fetched
+            cat.upload_params(t)
+            cat.enqueue()
+        cat.upload_params(tables[-1])
+        for _ in range(depth):                      # same table enqueued repeatedly: both buffers hold its result
+            cat.enqueue()
+        assert np.array_equal(cat.fetch(), plain.loglike(tables[-1]))
+    # a mixture catalogue in the denormal regime: the re-run flag word travels through the all-reduce in either buffer
+    g = load_golden("constant_bg_gaussian_fixed")
+    pm = g["pmember"].copy()
+    pm[:3] = 1.0
+    v = g["v"].copy()
+    v[:3] = [900.0, -1500.0, 4000.0]
+    gc = (float(g["ra_center"]), float(g["dec_center"]))
+    kw = dict(model=native.MODEL_CONST_BGFIXED, centre=gc, lnlike_bg=g["lnlike_background"], pmember=pm)
+    rows = g["values"][np.isfinite(g["lnprior"]) & (g["values"][:, 1] > 0)]
+    mix = native.Catalog(ctx1, g["ra"], g["dec"], v, g["verr"], **kw)
+    want = native.Catalog(native.default_context(), g["ra"], g["dec"], v, g["verr"], **kw).loglike(rows)
+    for _ in range(3):
+        got = mix.loglike(rows)
+        assert np.array_equal(np.isfinite(got), np.isfinite(want)) and np.all(np.isneginf(want))
+    assert mix.rerun_count == 3
+    mix.close()
     cat.close()
+    plain.close()
     ctx1.close()
 
 
