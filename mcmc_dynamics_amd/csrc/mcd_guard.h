@@ -75,8 +75,16 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
 //            lnlike_bg > -1e5, 0 <= pmember <= 1 (>= 2^-700 where lnlike_bg < -690);  density >= 0 (likewise), f_back >= 0, 2^-100 <= density + f_back <= 2^100
 // Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
 // expressions term by term.
+// per-call ranges fast_guard derives from the catalogue statistics and the parameter table (for fast_level)
+struct GuardRanges {
+    double n_min = 0, n_max = 0;        // cluster variance verr^2 + sigma_los^2
+    double nb_min = 0, nb_max = 0;      // background variance verr^2 + sigma_back^2 (BG_GAUSS)
+    double d_max = 0;                   // bound on |v - v_los| (and |v - v_back|)
+    double f_min = 0, f_max = 0;        // f_back (BG_GAUSS, BG_FIXED_DENSITY)
+};
+
 inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
-                       int64_t n_rows, double* n_min_out = nullptr, double* d_max_out = nullptr) {
+                       int64_t n_rows, GuardRanges* ranges = nullptr) {
     if (!st.stats_finite || n_rows == 0) return false;
     if (f32 && bg_kind(model) != BG_NONE) return false;      // f32 mixtures use the plain kernels
     const bool prof = is_profile(model);
@@ -119,8 +127,11 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
     if (!(d_max <= std::ldexp(1.0, 58))) return false;
     // sigma_los of the profile models decays to 0 at large r: only verr^2 bounds the variance from below
     const double n_min = st.e2_min + (prof ? 0.0 : s2_min), n_max = st.e2_max + s2_max;
-    if (n_min_out) *n_min_out = n_min;
-    if (d_max_out) *d_max_out = d_max;
+    if (ranges) {
+        ranges->n_min = n_min; ranges->n_max = n_max; ranges->d_max = d_max;
+        ranges->nb_min = st.e2_min + sb2_min; ranges->nb_max = st.e2_max + sb2_max;
+        ranges->f_min = f_min; ranges->f_max = f_max;
+    }
     if (prof && !(len_min >= std::ldexp(1.0, -100) && len_max <= std::ldexp(1.0, 100))) return false;   // a, r_peak > 0
     if (bg == BG_NONE) {
         if (f32)      // 4-star tree in f32: DEN <= 2^60, NUM <= 2^77
@@ -142,17 +153,24 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
     return true;
 }
 
-// Launch level for mcd::LaunchShape::fast: 0 plain kernels, 1 fast formulation, 2 narrow-range BGFIXED variant
-// (BgFixedAcc::add<.., NARROW>): additionally pmember < 1 for every star (so every mixture value y >= 1 - p >= 2^-53),
+// Launch level for mcd::LaunchShape::fast: 0 plain kernels, 1 fast formulation, 2 narrow-range variant.
+// BGFIXED (BgFixedAcc::add<.., NARROW>): additionally pmember < 1 for every star (so every mixture value y >= 1 - p >= 2^-53),
 // lnlike_bg >= -150 and norm >= 2^-60 (so y <= 1 + 2 norm^-1/2 e^150 < 2^250): four raw factors fit between rescales;
-// and |v - v_los|^2 <= 1e7 norm.
+// and |v - v_los|^2 <= 1e7 norm.  BGGAUSS / PROFILE_BGGAUSS (BgGaussAcc::add<.., NARROW>): see below.
 inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
                       int64_t n_rows) {
-    double n_min = 0.0, d_max = 0.0;
-    if (!fast_guard(st, model, free_centre, f32, k, params, n_rows, &n_min, &d_max)) return 0;
+    GuardRanges g;
+    if (!fast_guard(st, model, free_centre, f32, k, params, n_rows, &g)) return 0;
+    if (f32) return 1;
+    const double lo = 0x1p-60, hi = 0x1p60;
     // (d_max^2 <= 1e7 n_min: the exponent argument stays above -5e6, inside the int range of exp_tab without a clamp)
-    if (model == MODEL_BGFIXED && !f32 && st.lnbg_min >= -150.0 && st.pmember_max < 1.0 && n_min >= 0x1p-60 &&
-        d_max * d_max <= 1.0e7 * n_min)
+    if (model == MODEL_BGFIXED && st.lnbg_min >= -150.0 && st.pmember_max < 1.0 && g.n_min >= lo &&
+        g.d_max * g.d_max <= 1.0e7 * g.n_min)
+        return 2;
+    // BgGaussAcc::add<.., NARROW>: y >= the undamped term min(rho g, f g_b) >= 2^-20 2^-31 and y <= (rho + f) 2^31 <= 2^52
+    if (bg_kind(model) == BG_GAUSS && st.rho_min >= 0x1p-20 && st.rho_max <= 0x1p20 && g.f_min >= 0x1p-20 &&
+        g.f_max <= 0x1p20 && g.n_min >= lo && g.n_max <= hi && g.nb_min >= lo && g.nb_max <= hi &&
+        g.d_max * g.d_max <= 1.0e7 * std::min(g.n_min, g.nb_min))
         return 2;
     return 1;
 }

@@ -430,6 +430,20 @@ MCD_HD double ldexp_(double x, int k) {
     return std::ldexp(x, k);
 #endif
 }
+MCD_HD double fmin_(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmin(a, b);              // v_min_f64
+#else
+    return std::fmin(a, b);
+#endif
+}
+MCD_HD double fabs_(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fabs(a);                 // source modifier, no instruction
+#else
+    return std::fabs(a);
+#endif
+}
 MCD_HD double fmax_(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_fmax(a, b);              // v_max_f64
@@ -502,32 +516,44 @@ struct BgFixedAcc {
 //   y_i   = rho g + f gb e^{-delta}   (w <= wb)   or   rho g e^{-delta} + f gb   (w > wb),  delta = |wb - w| / 2
 //   with g = n^-1/2, w = d^2 g^2 (cluster) and gb, wb (background).  One exp with a non-positive argument.
 struct BgGaussAcc {
-    double sum_min;        // sum min(w, wb)
-    LogProduct ly;         // sum log y_i
+    double sum_min;        // sum min(w, wb)   (HALVED: sum of min(w, wb) / 2)
+    LogProduct ly;         // sum log y_i      (HALVED: y_i / sqrt(2))
     LogProduct lden;       // sum log(rho_i + f)
     int emin;              // as BgFixedAcc::emin: y_i < 2^-1000 needs the undamped component to be exactly zero
     MCD_HD void init() { sum_min = 0.0; ly.init(); lden.init(); emin = LogProduct::kTrackInit; }
     MCD_HD bool denormal() const { return emin < LogProduct::kTrackFloor; }
+    // HALVED: the caller passes 2 n and 2 nb: gh = g / sqrt(2), (d gh)^2 = w / 2, so that the exponent argument
+    //   -|wb/2 - w/2| = -delta needs no multiplication by -1/2; y comes out divided by sqrt(2) and min(w, wb) halved,
+    //   both undone by constants in finish().
+    // NARROW (host guard, mcd_guard.h: fast_level): density and f_back in [2^-20, 2^20], norms in [2^-60, 2^60], so
+    //   y >= the undamped term >= 2^-51 and y <= 2^52 -- four raw factors between rescales, no mantissa/exponent split,
+    //   no denormal tracking; |d|^2 <= 1e7 norm, so the exponent argument needs no clamp; one-constant range reduction.
+    template <bool HALVED = false, bool NARROW = false>
     MCD_HD void add(double d, double n, double db, double nb, double rho, double f, const double* __restrict__ exptab) {
         const double g = rsqrt_nr(n), gb = rsqrt_nr(nb);
         const double dg = d * g, dbg = db * gb;
         const double w = dg * dg, wb = dbg * dbg;
-        const bool cluster_big = w <= wb;                 // cluster exponent -w/2 is the larger one
-        const double delta = cluster_big ? (wb - w) : (w - wb);
+        const double t = wb - w;
+        const bool cluster_big = t >= 0.0;                 // w <= wb: the cluster exponent is the larger one
+        const double u0 = HALVED ? -fabs_(t) : -0.5 * fabs_(t);
         int k;                                            // e^-1100 == 0 in f64; the clamp keeps k inside int range
-        const double er = exp_tab(fmax_(-0.5 * delta, -1100.0), k, exptab);
+        const double er = exp_tab<!NARROW>(NARROW ? u0 : fmax_(u0, -1100.0), k, exptab);
         const double e = ldexp_(er, k);                    // k <= 0: underflows to 0 inside ldexp
         const double a = rho * g, b = f * gb;
         // if the undamped component is exactly zero (f_back = 0 or density = 0) and e^{-delta} underflows, y = 0 and
         // lnL = -inf -- the same as the reference's log-sum-exp about the larger exponent (constant.py:320-323).
         const double y = cluster_big ? fma_(b, e, a) : fma_(a, e, b);
-        ly.mul_any_track(y, emin);
+        if constexpr (NARROW) ly.mul(y);
+        else ly.mul_any_track(y, emin);
         lden.mul(rho + f);
-        sum_min += cluster_big ? w : wb;
+        sum_min += fmin_(w, wb);
     }
     MCD_HD void rescale() { ly.rescale(); lden.rescale(); }
+    template <bool HALVED = false>
     MCD_HD double finish(int64_t count) {
-        return fma_(-(double)count, kHalfLn2Pi, -0.5 * sum_min) + (ly.value() - lden.value());
+        // HALVED: log y = log(y / sqrt 2) + 1/2 log 2 per star, and sum_min already carries its factor 1/2
+        const double per_star = HALVED ? kHalfLn2Pi - 0.5 * kLn2 : kHalfLn2Pi;
+        return fma_(-(double)count, per_star, HALVED ? -sum_min : -0.5 * sum_min) + (ly.value() - lden.value());
     }
 };
 
@@ -536,20 +562,6 @@ struct BgGaussAcc {
 //   e_j = -(c_j - v)^2 h,  h = 1 / (2 (verr^2 + sigma_int^2));   slice result: nearest distance + sum_j exp(e_j - e_max)
 // Two passes over the slice: the nearest comparison star gives the largest exponent exactly, every term of the
 // second pass then has a non-positive exponent and the nearest star contributes exactly 1.
-MCD_HD double fmin_(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_fmin(a, b);              // v_min_f64
-#else
-    return std::fmin(a, b);
-#endif
-}
-MCD_HD double fabs_(double a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_fabs(a);                 // source modifier, no instruction
-#else
-    return std::fabs(a);
-#endif
-}
 struct KdeLane {
     double v, h, d2min, sum;
     MCD_HD void init(double v_, double verr, double sigma_int2) {
@@ -631,7 +643,8 @@ MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T&
 MCD_HD constexpr bool exp_table_is_sqrt2_scaled(int model) { return model == MODEL_BGFIXED; }
 
 // FAST: 0 = plain (the reference's expressions term by term), 1 = fast formulation, 2 = fast formulation with the
-// narrow-range product of BgFixedAcc::add (MODEL_BGFIXED only; otherwise the same as 1).
+// narrow-range products of BgFixedAcc::add (MODEL_BGFIXED) / BgGaussAcc::add (MODEL_BGGAUSS, MODEL_PROFILE_BGGAUSS);
+// for the other models the same as 1.
 template <int MODEL, bool FREE, class T, class A, int FAST>
 MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w, bool& denormal,
                             const double* __restrict__ exptab) {
@@ -761,6 +774,10 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         result = acc.finish_density();
         denormal = acc.denormal();
     } else if constexpr (BG == BG_GAUSS && FAST) {
+        // MODEL_BGGAUSS has norm = verr^2 + sigma^2 and verr^2 + sigma_back^2: doubled norms are one FMA each (HALVED form)
+        constexpr bool HALVED = MODEL == MODEL_BGGAUSS;
+        constexpr bool NARROW = FAST == 2;
+        const double s2x2 = (double)w.s2 + (double)w.s2, sb2x2 = (double)w.sb2 + (double)w.sb2;
         BgGaussAcc acc;
         acc.init();
         const int n4 = count >> 2;
@@ -770,17 +787,19 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 const double* rr = r + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
-                acc.add(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb, exptab);
+                if constexpr (HALVED) acc.add<true, NARROW>(d, fma_(2.0, rr[1], s2x2), rr[0] - w.vb, fma_(2.0, rr[1], sb2x2), rr[XB], w.fb, exptab);
+                else acc.add<false, NARROW>(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb, exptab);
             }
             acc.rescale();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
-            acc.add(d, n, r[0] - w.vb, r[1] + w.sb2, r[XB], w.fb, exptab);
+            if constexpr (HALVED) acc.add<true, NARROW>(d, fma_(2.0, r[1], s2x2), r[0] - w.vb, fma_(2.0, r[1], sb2x2), r[XB], w.fb, exptab);
+            else acc.add<false, NARROW>(d, n, r[0] - w.vb, r[1] + w.sb2, r[XB], w.fb, exptab);
             acc.rescale();
         }
-        result = acc.finish(count);
+        result = acc.finish<HALVED>(count);
         denormal = acc.denormal();
     } else {
         A sum = 0;

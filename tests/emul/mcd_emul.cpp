@@ -72,10 +72,10 @@ extern "C" int emul_loglike(int model, int free_centre, int fast, int64_t n, con
 #define CASE(M, F, X) if (model == M && (free_centre != 0) == F && (fast != 0) == X && fast != 2) { run<M, F, X ? 1 : 0>(n, recs, wpar, W, chunk_len, out); return 0; }
     FOR_ALL(0) FOR_ALL(1) FOR_ALL(2) FOR_ALL(3) FOR_ALL(4) FOR_ALL(5)
 #undef CASE
-    if (model == 1 && fast == 2) {            // narrow-range BGFIXED variant
-        if (free_centre) run<1, true, 2>(n, recs, wpar, W, chunk_len, out);
-        else run<1, false, 2>(n, recs, wpar, W, chunk_len, out);
-        return 0;
+    if (fast == 2) {                          // narrow-range variants
+#define NARROW_CASE(M) if (model == M) { if (free_centre) run<M, true, 2>(n, recs, wpar, W, chunk_len, out); else run<M, false, 2>(n, recs, wpar, W, chunk_len, out); return 0; }
+        NARROW_CASE(1) NARROW_CASE(2) NARROW_CASE(4)
+#undef NARROW_CASE
     }
     return -1;
 }

@@ -77,6 +77,16 @@ def test_walker_gaussian_background_golden(native, ctx, which):
     got = cat.loglike(g["values"])
     want, ok = _likelihood_part(g)
     assert rel_err(got[ok], want[ok]) < RTOL
+    # the three kernel families on the rows every one of them admits (f_back > 0, sigma > 0: narrow-range variant eligible)
+    names = [str(x) for x in g["names"]]
+    inner = ok & (g["values"][:, names.index("f_back")] > 1e-6) & (g["values"][:, names.index("sigma_max")] > 0)
+    assert inner.sum() >= 6
+    for fast_path, level in ((1, 2), (2, 1), (0, 0)):
+        cat.set_option("fast_path", fast_path)
+        res = cat.loglike(g["values"][inner])
+        assert cat.fast_level == level
+        assert rel_err(res, want[inner]) < RTOL
+    cat.set_option("fast_path", 1)
     # membership probabilities, constant.py:366-374
     row = int(g["membership_row"])
     mem = cat.membership(g["values"][row])

@@ -215,3 +215,28 @@ def test_narrow_range_level_conditions():
     plain = emul.loglike(edge, rows, 1, centre, 0, 64)
     assert np.all(np.isfinite(plain)) and rel_err(narrow, plain) < RTOL
     assert rel_err(emul.loglike(edge, rows, 1, centre, 1, 64), plain) < RTOL
+
+
+@pytest.mark.parametrize("name,model", [("constant_gb_fixed", 2), ("constant_gb_free", 2), ("model_fit_gb_fixed", 4),
+                                        ("model_fit_gb_free", 4)])
+@pytest.mark.parametrize("chunk_len", [64, 100000])
+def test_narrow_range_gaussian_background_variant_matches_reference(name, model, chunk_len):
+    """BgGaussAcc::add<.., NARROW> (raw products, no clamp, one-constant range reduction; density and f_back within
+    [2^-20, 2^20]) against lnprob of the reference's ConstantFitGB / ModelFitGB (constant.py:293-364, model.py:391-456)."""
+    g = load_golden(name)
+    free = name.endswith("free")
+    cat = {k: g[k] for k in ("ra", "dec", "v", "verr", "density")}
+    centre = None if free else (float(g["ra_center"]), float(g["dec_center"]))
+    names = [str(x) for x in g["names"]]
+    f = g["values"][:, names.index("f_back")]
+    ok = np.isfinite(g["lnprob"]) & (f > 1e-6) & (g["values"][:, names.index("sigma_max")] > 0)
+    values = emul.abi_columns(g["names"], g["values"], model, free)[ok]
+    assert ok.sum() >= 6 and emul.fast_level(cat, values, model, centre) == 2
+    got = emul.loglike(cat, values, model, centre, 2, chunk_len)
+    assert rel_err(got, g["lnprob"][ok]) < RTOL
+    zero_f = values.copy()
+    zero_f[0, -1] = 0.0                                    # f_back = 0: the undamped term can vanish -> general form
+    assert emul.fast_level(cat, zero_f, model, centre) == 1
+    sparse = dict(cat, density=cat["density"].copy())
+    sparse["density"][7] = 0.0
+    assert emul.fast_level(sparse, values, model, centre) == 1

@@ -52,6 +52,9 @@ def main():
                         cat["pmember"] = np.minimum(cat["pmember"], 1.0 - 2.0 ** -float(rng.integers(1, 54)))
                     kw = dict(lnlike_bg=cat["lnlike_bg"], pmember=cat["pmember"])
                 elif model in (2, 4):
+                    if trial % 2:                          # no empty component: the narrow-range variant becomes eligible
+                        cat["density"] = np.maximum(cat["density"], 10.0 ** -rng.uniform(0, 6.0))
+                        params[:, -1] = np.maximum(params[:, -1], 10.0 ** -rng.uniform(0, 6.0))
                     kw = dict(density=cat["density"])
                 elif model == 5:
                     kw = dict(lnlike_bg=cat["lnlike_bg"], density=cat["density"])

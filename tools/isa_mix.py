@@ -22,6 +22,7 @@ SLOT_NS = 2.33
 KERNELS = [  # (template tag, name, stars per loop iteration)
     ("ILi0ELb0EddLi1E", "CONST fixed centre", 8), ("ILi0ELb1EddLi1E", "CONST free centre", 8),
     ("ILi1ELb0EddLi1E", "BGFIXED fixed centre", 4), ("ILi1ELb0EddLi2E", "BGFIXED fixed, narrow", 4), ("ILi2ELb0EddLi1E", "BGGAUSS fixed centre", 4),
+    ("ILi2ELb0EddLi2E", "BGGAUSS fixed, narrow", 4),
     ("ILi3ELb0EddLi1E", "PROFILE fixed centre", 8), ("ILi4ELb0EddLi1E", "PROFILE_BGGAUSS fixed", 4),
     ("ILi5ELb0EddLi1E", "PROFILE_BGDENS fixed", 4), ("ILi0ELb0EffLi1E", "CONST fixed, f32", 16),
 ]
