@@ -51,9 +51,9 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
             // vanishing prior there also makes the reference's log-sum-exp underflow (runner.py:282-284 gives -inf for
             // p == 0): the plain kernels reproduce that literally.
             if (lnbg[i] < -690.0 && !(pm >= 0x1p-700)) ok = false;
-            b_min = std::min(b_min, lnbg[i]);
             pm_max = std::max(pm_max, pm);
         }
+        if (bg == BG_FIXED || bg == BG_FIXED_DENSITY) b_min = std::min(b_min, lnbg[i]);
         if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) {
             const double rho = density[i];
             if (!(std::isfinite(rho) && rho >= 0.0)) ok = false;
@@ -166,6 +166,10 @@ inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool 
     // (d_max^2 <= 1e7 n_min: the exponent argument stays above -5e6, inside the int range of exp_tab without a clamp)
     if (model == MODEL_BGFIXED && st.lnbg_min >= -150.0 && st.pmember_max < 1.0 && g.n_min >= lo &&
         g.d_max * g.d_max <= 1.0e7 * g.n_min)
+        return 2;
+    // BgFixedAcc::add_density<NARROW>: y = f + rho g e^u >= f >= 2^-20 and <= 2^20 + 2^20 2^31 e^120 < 2^225
+    if (bg_kind(model) == BG_FIXED_DENSITY && st.lnbg_min >= -120.0 && st.rho_max <= 0x1p20 && g.f_min >= 0x1p-20 &&
+        g.f_max <= 0x1p20 && g.n_min >= lo && g.d_max * g.d_max <= 1.0e7 * g.n_min)
         return 2;
     // BgGaussAcc::add<.., NARROW>: y >= the undamped term min(rho g, f g_b) >= 2^-20 2^-31 and y <= (rho + f) 2^31 <= 2^52
     if (bg_kind(model) == BG_GAUSS && st.rho_min >= 0x1p-20 && st.rho_max <= 0x1p20 && g.f_min >= 0x1p-20 &&

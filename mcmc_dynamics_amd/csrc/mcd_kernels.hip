@@ -274,7 +274,7 @@ hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* re
     const double launch_tag = sh.launch_tag;
     switch (sh.precision) {
         case 0:
-            if constexpr (MODEL == MODEL_BGFIXED || bg_kind(MODEL) == BG_GAUSS) {
+            if constexpr (bg_kind(MODEL) != BG_NONE) {
                 if (sh.fast == 2)
                     return launch_one<MODEL, FREE, double, double, 2>(s, records, chunks, n_chunks, wpar, partials,
                                                                       n_walkers, uniform_len, n_records, rerun_flag, launch_tag);

@@ -468,8 +468,9 @@ struct BgFixedAcc {
     // An exact y_i == 0 is flagged too: the reference applies its prefactors inside the exponent (e^{m - M}), this path
     // outside (g e^u), so the two underflow at slightly different outliers (found by tools/fuzz_gpu.py).
     MCD_HD bool denormal() const { return emin < LogProduct::kTrackFloor; }
+    template <bool NARROW = false>
     MCD_HD void add_density(double d, double n, double rho, double f, double nbp, const double* __restrict__ exptab) {
-        add<false>(d, n, rho, f, nbp, exptab);   // f_back is a per-walker (VGPR) value here
+        add<false, false, NARROW>(d, n, rho, f, nbp, exptab);   // f_back is a per-walker (VGPR) value here
         lden.mul(rho + f);
     }
     // HALVED: the caller passes 2 n instead of n and the table sqrt(2) 2^(j/256) (MCD_EXP_TABLE_SQRT2_VALUES):
@@ -643,8 +644,8 @@ MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T&
 MCD_HD constexpr bool exp_table_is_sqrt2_scaled(int model) { return model == MODEL_BGFIXED; }
 
 // FAST: 0 = plain (the reference's expressions term by term), 1 = fast formulation, 2 = fast formulation with the
-// narrow-range products of BgFixedAcc::add (MODEL_BGFIXED) / BgGaussAcc::add (MODEL_BGGAUSS, MODEL_PROFILE_BGGAUSS);
-// for the other models the same as 1.
+// narrow-range products of BgFixedAcc::add (MODEL_BGFIXED, MODEL_PROFILE_BGDENS) / BgGaussAcc::add (MODEL_BGGAUSS,
+// MODEL_PROFILE_BGGAUSS); for the models without background the same as 1.
 template <int MODEL, bool FREE, class T, class A, int FAST>
 MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w, bool& denormal,
                             const double* __restrict__ exptab) {
@@ -752,6 +753,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         result = acc.finish();
         denormal = acc.denormal();
     } else if constexpr (BG == BG_FIXED_DENSITY && FAST) {
+        constexpr bool NARROW = FAST == 2;          // f_back >= 2^-20 bounds every mixture value from below (mcd_guard.h)
         BgFixedAcc acc;
         acc.init();
         const int n4 = count >> 2;
@@ -761,14 +763,14 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 const double* rr = r + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
-                acc.add_density(d, n, rr[XB + 2], w.fb, rr[XB + 1], exptab);
+                acc.add_density<NARROW>(d, n, rr[XB + 2], w.fb, rr[XB + 1], exptab);
             }
             acc.rescale_density();
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
-            acc.add_density(d, n, r[XB + 2], w.fb, r[XB + 1], exptab);
+            acc.add_density<NARROW>(d, n, r[XB + 2], w.fb, r[XB + 1], exptab);
             acc.rescale_density();
         }
         result = acc.finish_density();

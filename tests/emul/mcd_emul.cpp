@@ -74,7 +74,7 @@ extern "C" int emul_loglike(int model, int free_centre, int fast, int64_t n, con
 #undef CASE
     if (fast == 2) {                          // narrow-range variants
 #define NARROW_CASE(M) if (model == M) { if (free_centre) run<M, true, 2>(n, recs, wpar, W, chunk_len, out); else run<M, false, 2>(n, recs, wpar, W, chunk_len, out); return 0; }
-        NARROW_CASE(1) NARROW_CASE(2) NARROW_CASE(4)
+        NARROW_CASE(1) NARROW_CASE(2) NARROW_CASE(4) NARROW_CASE(5)
 #undef NARROW_CASE
     }
     return -1;

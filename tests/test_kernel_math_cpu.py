@@ -240,3 +240,22 @@ def test_narrow_range_gaussian_background_variant_matches_reference(name, model,
     sparse = dict(cat, density=cat["density"].copy())
     sparse["density"][7] = 0.0
     assert emul.fast_level(sparse, values, model, centre) == 1
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_narrow_range_constant_background_profile_variant(which):
+    """ModelFitConstantBackground (model.py:565-623) through BgFixedAcc::add_density<NARROW> (f_back >= 2^-20 bounds the
+    mixture values from below, lnL_bg >= -120 from above) against lnprob of the reference."""
+    g = load_golden("model_fit_cb_" + which)
+    free = which == "free"
+    cat = {k: g[k] for k in ("ra", "dec", "v", "verr", "density")}
+    cat["lnlike_bg"] = g["lnlike_background"]
+    centre = None if free else (float(g["ra_center"]), float(g["dec_center"]))
+    names = [str(x) for x in g["names"]]
+    ok = np.isfinite(g["lnprob"]) & (g["values"][:, names.index("f_back")] > 1e-6) & (g["values"][:, names.index("sigma_max")] > 0)
+    values = emul.abi_columns(g["names"], g["values"], 5, free)[ok]
+    assert ok.sum() >= 6 and emul.fast_level(cat, values, 5, centre) == 2
+    assert rel_err(emul.loglike(cat, values, 5, centre, 2, 64), g["lnprob"][ok]) < RTOL
+    zero_f = values.copy()
+    zero_f[0, -1] = 0.0
+    assert emul.fast_level(cat, zero_f, 5, centre) == 1

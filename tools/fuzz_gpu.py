@@ -57,6 +57,8 @@ def main():
                         params[:, -1] = np.maximum(params[:, -1], 10.0 ** -rng.uniform(0, 6.0))
                     kw = dict(density=cat["density"])
                 elif model == 5:
+                    if trial % 2:
+                        params[:, -1] = np.maximum(params[:, -1], 10.0 ** -rng.uniform(0, 6.0))
                     kw = dict(lnlike_bg=cat["lnlike_bg"], density=cat["density"])
                 centre = CENTRE
                 if free:
