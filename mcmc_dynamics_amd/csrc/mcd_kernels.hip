@@ -66,13 +66,16 @@ __global__ __launch_bounds__(kBlock) void prepare_records_kernel(RawColumns raw,
     }
     const int bg = bg_kind(model);
     if (bg == BG_FIXED) {
+        // fast paths: exponent offset with the prior weight folded in, log p - (b + 1/2 log 2pi); the floor keeps it finite
+        // for p == 0 (e^-1e5 is an exact 0 in f64, so y = 1 - p exactly as it must)
         const double b = raw.lnbg[i], pm = raw.pmember[i];
-        r[k] = (T)b; r[k + 1] = (T)pm; r[k + 2] = (T)(1.0 - pm); r[k + 3] = (T)(-(b + kHalfLn2Pi));
+        r[k] = (T)b; r[k + 1] = (T)pm; r[k + 2] = (T)(1.0 - pm); r[k + 3] = (T)fmax(log(pm) - (b + kHalfLn2Pi), -1.0e5);
     } else if (bg == BG_GAUSS) {
         r[k] = (T)raw.density[i]; r[k + 1] = (T)0;
     } else if (bg == BG_FIXED_DENSITY) {
         const double b = raw.lnbg[i];
-        r[k] = (T)b; r[k + 1] = (T)(-(b + kHalfLn2Pi)); r[k + 2] = (T)raw.density[i]; r[k + 3] = (T)0;
+        r[k] = (T)b; r[k + 1] = (T)fmax(log(raw.density[i]) - (b + kHalfLn2Pi), -1.0e5); r[k + 2] = (T)raw.density[i];
+        r[k + 3] = (T)0;
     }
 }
 

@@ -453,7 +453,7 @@ MCD_HD double fmax_(double a, double b) {
 }
 
 // MODEL_BGFIXED: lnL_i = b_i + log((1 - p_i) + p_i t_i),  t_i = exp(m_i - b_i) = g exp(-1/2 q g^2 - b'_i),
-// b'_i = b_i + 1/2 log 2pi  (the record carries nbp = -b'_i).  Same value as runner.py:280-286.
+// b'_i = b_i + 1/2 log 2pi  (the record carries nbp = -b'_i + log p_i).  Same value as runner.py:280-286.
 // BG_FIXED_DENSITY (model.py:565-623) is the same with p -> rho_i, (1 - p) -> f_back and an extra -log(rho_i + f_back).
 struct BgFixedAcc {
     LogProduct l;          // sum log y_i   (sum b_i is walker-independent: added once per parameter set by the reduce kernel)
@@ -470,7 +470,7 @@ struct BgFixedAcc {
     MCD_HD bool denormal() const { return emin < LogProduct::kTrackFloor; }
     template <bool NARROW = false>
     MCD_HD void add_density(double d, double n, double rho, double f, double nbp, const double* __restrict__ exptab) {
-        add<false, false, NARROW>(d, n, rho, f, nbp, exptab);   // f_back is a per-walker (VGPR) value here
+        add<false, false, NARROW>(d, n, f, nbp, exptab);        // f_back is a per-walker (VGPR) value here
         lden.mul(rho + f);
     }
     // HALVED: the caller passes 2 n instead of n and the table sqrt(2) 2^(j/256) (MCD_EXP_TABLE_SQRT2_VALUES):
@@ -481,7 +481,10 @@ struct BgFixedAcc {
     // hence four raw factors can be multiplied between two rescales without the per-star mantissa/exponent split,
     // without the k > 1000 exponent carry and without the denormal-regime tracking (7 VALU instructions per term less).
     template <bool UNIFORM_OMP = true, bool HALVED = false, bool NARROW = false>
-    MCD_HD void add(double d, double n, double p, double omp, double nbp, const double* __restrict__ exptab) {
+    // The prior weight p of the cluster component is folded into the exponent by the record preparation:
+    // nbp = -(b + 1/2 log 2pi) + log p (floored at -1e5, where e^u is an exact 0: p == 0 gives y = 1 - p = 1), so
+    // y = (1 - p) + g e^{u} with u = -1/2 d^2 g^2 + nbp needs no multiplication by p.
+    MCD_HD void add(double d, double n, double omp, double nbp, const double* __restrict__ exptab) {
         const double g = rsqrt_nr(n);
         const double dg = d * g;
         // u <= 1e5 by the host guard (|lnL_bg| <= 1e5); below -1100 e^u is an exact 0 in f64 (as in the reference),
@@ -492,16 +495,16 @@ struct BgFixedAcc {
         int k;
         const double er = exp_tab<!NARROW>(u, k, exptab);
         if constexpr (NARROW) {
-            const double y = UNIFORM_OMP ? fma_sgpr_addend(p * g, ldexp_(er, k), omp) : fma_(p * g, ldexp_(er, k), omp);
+            const double y = UNIFORM_OMP ? fma_sgpr_addend(g, ldexp_(er, k), omp) : fma_(g, ldexp_(er, k), omp);
             l.mul(y);
             return;
         }
-        // y = (1 - p) + p g e^r 2^k.  k > 1000 (cluster likelihood e^693 times the background's) is carried in the
+        // y = (1 - p) + g e^r 2^k.  k > 1000 (cluster likelihood e^693 times the background's) is carried in the
         // integer part of the product: there the (1 - p) term is below 2^-900 of y and drops out exactly as in f64.
         // k < -1074 underflows inside ldexp; with p == 1 exactly that gives y = 0 and lnL = -inf, which is also what
         // the reference returns there (runner.py:283: log(1 * exp(m - b) + 0) with exp underflowing).
         const int kc = k > 1000 ? 1000 : k;
-        const double y = UNIFORM_OMP ? fma_sgpr_addend(p * g, ldexp_(er, kc), omp) : fma_(p * g, ldexp_(er, kc), omp);
+        const double y = UNIFORM_OMP ? fma_sgpr_addend(g, ldexp_(er, kc), omp) : fma_(g, ldexp_(er, kc), omp);
         l.mul_any_track(y, emin);
         l.e32 += k - kc;
     }
@@ -740,7 +743,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
                 if constexpr (HALVED) n = fma_(2.0, rr[1], s2x2);
-                acc.add<true, HALVED, NARROW>(d, n, rr[XB + 1], rr[XB + 2], rr[XB + 3], exptab);
+                acc.add<true, HALVED, NARROW>(d, n, rr[XB + 2], rr[XB + 3], exptab);
             }
             acc.rescale();
         }
@@ -748,7 +751,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
             if constexpr (HALVED) n = fma_(2.0, r[1], s2x2);
-            acc.add<true, HALVED, NARROW>(d, n, r[XB + 1], r[XB + 2], r[XB + 3], exptab);
+            acc.add<true, HALVED, NARROW>(d, n, r[XB + 2], r[XB + 3], exptab);
             acc.rescale();
         }
         result = acc.finish();

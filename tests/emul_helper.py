@@ -59,12 +59,14 @@ def pack_records(cat, model, centre):
     bg = BG_OF[model]
     if bg == 1:
         b, p = cat["lnlike_bg"], cat["pmember"]
-        cols += [b, p, 1.0 - p, -(b + HALF_LN_2PI)]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cols += [b, p, 1.0 - p, np.fmax(np.log(p) - (b + HALF_LN_2PI), -1.0e5)]
     elif bg == 2:
         cols += [cat["density"], np.zeros(n)]
     elif bg == 3:
         b = cat["lnlike_bg"]
-        cols += [b, -(b + HALF_LN_2PI), cat["density"], np.zeros(n)]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cols += [b, np.fmax(np.log(cat["density"]) - (b + HALF_LN_2PI), -1.0e5), cat["density"], np.zeros(n)]
     return np.ascontiguousarray(np.stack(cols, axis=1), dtype=np.float64)
 
 
