@@ -57,8 +57,10 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--clock-ramp-seconds", type=float, default=0.4,
+                    help="untimed launches before the W warm-up steps so that the GPU is at its sustained clocks")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--stars", type=int, default=None, help="stars per GPU (override)")
     ap.add_argument("--walkers", type=int, default=None)
@@ -305,16 +307,37 @@ def main():
             gpu_cat = build_catalog(native, ctx, synthetic, None, cat, model, args.precision, bin_offsets)
             gpu_cat.upload_params(pos)
     gpu_cat.set_option("timing", 2)
+    gpu_cat.set_option("timing_reserve", min(65536, max(args.steps, args.warmup)))   # no hipEventCreate inside the timed region
 
     def barrier():
         gpu_cat.sync()
         if dist is not None:
             dist.barrier()
 
+    # Clock ramp (untimed, before the W warm-up steps): the GPU needs some 100 ms of load to reach its sustained clocks --
+    # measured kernel time 270 us in the first 20 launches after idle, 222 us once settled.  Every rank runs the same
+    # number of launches (the all-reduce is collective).
+    ramp_steps = 0
+    if args.clock_ramp_seconds > 0:
+        gpu_cat.enqueue()
+        gpu_cat.sync()
+        t_r = time.perf_counter()
+        for _ in range(8):
+            gpu_cat.enqueue()
+        gpu_cat.sync()
+        per_step = max((time.perf_counter() - t_r) / 8, 1e-6)
+        ramp_steps = int(min(20000, args.clock_ramp_seconds / per_step))
+        if dist is not None:
+            import torch
+            t = torch.tensor([ramp_steps], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ramp_steps = int(t[0])
+        for _ in range(ramp_steps):
+            gpu_cat.enqueue()
     for _ in range(args.warmup):
         gpu_cat.enqueue()
     barrier()
-    gpu_cat.timing_collect()                         # drop warm-up launches
+    gpu_cat.timing_collect()                         # drop ramp and warm-up launches
 
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -390,7 +413,7 @@ def main():
 
     out = {
         "metric": "star-walker log-L terms/sec", "value": value, "unit": "terms/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": ramp_steps,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "stars_per_gpu": len(cat["v"]), "stars_total": total_stars, "walkers": n_walkers,

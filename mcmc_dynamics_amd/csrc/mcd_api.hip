@@ -874,6 +874,20 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         for (Shard& sh : cat->shards) sh.ring_used = 0;
         return MCD_OK;
     }
+    if (!std::strcmp(key, "timing_reserve")) {
+        // create the per-launch event pairs of "timing" = 2 ahead of a measured loop (hipEventCreate costs microseconds)
+        if (value < 0 || value > ((int64_t)1 << 16)) return fail(MCD_ERR_INVALID, "timing_reserve: 0 .. 65536 launches");
+        for (Shard& sh : cat->shards) {
+            MCD_HIP(hipSetDevice(cat->ctx->slots[sh.slot].device));
+            while ((int64_t)sh.ring.size() < value) {
+                hipEvent_t a, b;
+                MCD_HIP(hipEventCreate(&a));
+                if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return fail(MCD_ERR_HIP, "hipEventCreate"); }
+                sh.ring.emplace_back(a, b);
+            }
+        }
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "fast_path")) {
         if (value < 0 || value > 2) return fail(MCD_ERR_INVALID, "fast_path: 0 (plain), 1 (guarded, default) or 2 (guarded, no narrow variant)");
         cat->allow_fast = (int)value;
