@@ -195,3 +195,31 @@ def test_single_stars_background_matches_reference():
         got = oracle.faithful_constant_lnlike(cat, *row, float(g["ra_center"]), float(g["dec_center"]),
                                               lnlike_background=lnbg, pmember=g["pmember"])
         assert abs(got - want) <= RTOL * abs(want)
+
+
+def test_c1_plumbing_on_the_cpu_path():
+    """BASELINE config C1: example/data catalogue, constant-dispersion model, centre fixed, 32 walkers x
+    100 steps with the stretch-move driver on the CPU restatement of the reference's lnprob -- no GPU.  Pass = finite chain,
+    acceptance fraction in (0.1, 0.9), posterior medians stable across seeds."""
+    from mcmc_dynamics_amd.sampler import EnsembleSampler
+    g = load_golden("example_catalog")
+    cat = _cat(g)
+    rc, dc = float(g["ra_center"]), float(g["dec_center"])
+
+    def lnprob(x):                                     # flat priors of config/constant.json: sigma_max >= 0
+        out = np.full(len(x), -np.inf)
+        ok = x[:, 1] >= 0
+        out[ok] = oracle.batched_constant_lnlike(cat, x[ok], rc, dc)
+        return out
+
+    medians = []
+    for seed in (1, 2):
+        rng = np.random.default_rng(seed)
+        pos = np.column_stack([rng.normal(10, 2, 32), rng.lognormal(2.7, 0.3, 32), rng.normal(0, 2, 32), rng.normal(0, 2, 32)])
+        s = EnsembleSampler(32, 4, lnprob, vectorize=True, seed=seed)
+        s.run_mcmc(pos, 100)
+        assert s.chain.shape == (32, 100, 4) and np.all(np.isfinite(s.chain)) and np.all(np.isfinite(s.lnprobability))
+        assert 0.1 < s.acceptance_fraction.mean() < 0.9
+        medians.append(np.median(s.get_chain(discard=60, flat=True), axis=0))
+    spread = np.abs(medians[0] - medians[1])
+    assert spread[1] < 0.15 * medians[0][1] and np.all(spread[[0, 2, 3]] < 3.0), (medians, spread)
