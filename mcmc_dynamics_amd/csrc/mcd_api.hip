@@ -543,7 +543,7 @@ int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(MCD_ERR_NO_DEVICE, "no HIP device visible");
     if (n_dev > count) return fail(MCD_ERR_NO_DEVICE, "more devices requested than visible");
-    std::unique_ptr<mcd_ctx> ctx(new (std::nothrow) mcd_ctx());
+    std::unique_ptr<mcd_ctx, int (*)(mcd_ctx*)> ctx(new (std::nothrow) mcd_ctx(), &mcd_ctx_destroy);   // streams / communicators released on every error path
     if (!ctx) return fail(MCD_ERR_INVALID, "out of memory");
     ctx->slots.resize(n_dev);
     std::vector<int> ids(n_dev);
@@ -583,7 +583,7 @@ int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(MCD_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= count) return fail(MCD_ERR_NO_DEVICE, "device index out of range");
-    std::unique_ptr<mcd_ctx> ctx(new (std::nothrow) mcd_ctx());
+    std::unique_ptr<mcd_ctx, int (*)(mcd_ctx*)> ctx(new (std::nothrow) mcd_ctx(), &mcd_ctx_destroy);   // streams / communicators released on every error path
     if (!ctx) return fail(MCD_ERR_INVALID, "out of memory");
     ctx->slots.resize(1);
     int rc = make_slot(device, &ctx->slots[0]);
