@@ -98,6 +98,7 @@ struct WorkSet {
     int uniform_len = 0;               // > 0 when the chunk table is arithmetic (single set, equal lengths)
     mcd::Chunk* d_chunks = nullptr;
     int64_t* d_offsets = nullptr;      // [n_psets + 1] chunk offsets
+    uint8_t* d_chunk_general = nullptr;   // [n_chunks] chunks excluded from the narrow-range variant; null when there are none
     double* d_params = nullptr;        // [n_psets][W][K]
     void* d_wpar = nullptr;            // [n_psets][W][KD]
     double* d_partials = nullptr;      // [W][n_chunks]
@@ -183,6 +184,7 @@ int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 void free_workset(WorkSet& w) {
     if (w.d_chunks) (void)hipFree(w.d_chunks);
     if (w.d_offsets) (void)hipFree(w.d_offsets);
+    if (w.d_chunk_general) (void)hipFree(w.d_chunk_general);
     if (w.d_params) (void)hipFree(w.d_params);
     if (w.d_wpar) (void)hipFree(w.d_wpar);
     if (w.d_partials) (void)hipFree(w.d_partials);
@@ -256,10 +258,27 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
             uniform = chunks[i].begin == (int64_t)i * len && chunks[i].count == (int32_t)std::min<int64_t>(len, sh.n - (int64_t)i * len);
         if (uniform) w.uniform_len = (int)len;
     }
+    // chunks holding a star that rules out the narrow-range variants (stats.narrow_exceptions: ascending global indices)
+    std::vector<uint8_t> general;
+    const std::vector<int64_t>& exc = cat->stats.narrow_exceptions;
+    if (!exc.empty()) {
+        general.assign(chunks.size(), 0);
+        bool any = false;
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            const int64_t lo = sh.star_begin + chunks[i].begin, hi = lo + chunks[i].count;
+            const auto it2 = std::lower_bound(exc.begin(), exc.end(), lo);
+            if (it2 != exc.end() && *it2 < hi) { general[i] = 1; any = true; }
+        }
+        if (!any) general.clear();
+    }
     const int64_t n_out = cat->n_psets * n_walkers;
     const size_t term_bytes = cat->precision == MCD_F64 ? 8 : 4;
     auto allocate = [&]() -> hipError_t {
         hipError_t e;
+        if (!general.empty()) {
+            if ((e = hipMalloc(&w.d_chunk_general, general.size())) != hipSuccess) return e;
+            if ((e = hipMemcpy(w.d_chunk_general, general.data(), general.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+        }
         if ((e = hipMalloc(&w.d_chunks, std::max<size_t>(1, chunks.size()) * sizeof(mcd::Chunk))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_offsets, offs.size() * sizeof(int64_t))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_params, (size_t)n_out * cat->k * sizeof(double))) != hipSuccess) return e;
@@ -366,6 +385,7 @@ int enqueue(mcd_catalog* cat) {
         } else {
             w.buf = 0;
         }
+        shape.chunk_general = w.d_chunk_general;
         shape.rerun_flag = out_buf + n_out;
         if (coll) {
             w.launch_tag = 1.0;

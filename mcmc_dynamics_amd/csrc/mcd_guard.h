@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <vector>
 
 #include "mcd_math.h"
 
@@ -18,9 +19,21 @@ struct CatalogStats {
     double rho_min = 0, rho_max = 0;                // density range (BG_GAUSS / BG_FIXED_DENSITY)
     bool stats_finite = true;                       // v, verr all finite
     bool extras_ok = true;                          // background columns inside the fast-path ranges
-    double lnbg_min = 0;                            // BG_FIXED: smallest lnlike_bg, largest pmember (narrow variant)
-    double pmember_max = 0;
+    // Stars that rule out the narrow-range variants for the CHUNK that holds them (narrow_exception below), ascending
+    // indices; the kernel then takes the general fast form for those chunks only (LaunchShape::chunk_general).
+    std::vector<int64_t> narrow_exceptions;
+    bool narrow_possible = false;                   // at most 1/8 of the stars are exceptions (else: general form throughout)
 };
+
+// BGFIXED: a certain member (pmember == 1: the mixture value y = (1 - p) + ... has no floor) or lnL_bg < -150 (y can
+// exceed 2^250).  BGGAUSS family: density outside [2^-20, 2^20] (the undamped term rho g can vanish or explode).
+// PROFILE_BGDENS: lnL_bg < -120 or density > 2^20.
+inline bool narrow_exception(int bg, double lnbg, double pm, double rho) {
+    if (bg == BG_FIXED) return !(pm < 1.0) || lnbg < -150.0;
+    if (bg == BG_GAUSS) return !(rho >= 0x1p-20 && rho <= 0x1p20);
+    if (bg == BG_FIXED_DENSITY) return lnbg < -120.0 || !(rho <= 0x1p20);
+    return false;
+}
 
 // Gathered once at upload from the host columns (runner.py:261: norm = verr*verr + sigma*sigma).
 inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr, const double* lnbg,
@@ -29,7 +42,6 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
     double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
     double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
     bool finite = true, ok = true;
-    double b_min = std::numeric_limits<double>::infinity(), pm_max = 0.0;
     for (int64_t i = 0; i < n; ++i) {
         const double e2 = verr[i] * verr[i];
         const double av = std::fabs(v[i]);
@@ -51,9 +63,7 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
             // vanishing prior there also makes the reference's log-sum-exp underflow (runner.py:282-284 gives -inf for
             // p == 0): the plain kernels reproduce that literally.
             if (lnbg[i] < -690.0 && !(pm >= 0x1p-700)) ok = false;
-            pm_max = std::max(pm_max, pm);
         }
-        if (bg == BG_FIXED || bg == BG_FIXED_DENSITY) b_min = std::min(b_min, lnbg[i]);
         if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) {
             const double rho = density[i];
             if (!(std::isfinite(rho) && rho >= 0.0)) ok = false;
@@ -61,11 +71,14 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
             r_min = std::min(r_min, rho);
             r_max = std::max(r_max, rho);
         }
+        if (bg != BG_NONE && narrow_exception(bg, lnbg ? lnbg[i] : 0.0, pmember ? pmember[i] : 0.0, density ? density[i] : 1.0))
+            st.narrow_exceptions.push_back(i);
     }
     if (n == 0) { e2_min = 0.0; r_min = 0.0; }
     st.e2_min = e2_min; st.e2_max = e2_max; st.v_abs_max = v_abs; st.stats_finite = finite;
     st.extras_ok = ok; st.rho_min = r_min; st.rho_max = r_max;
-    st.lnbg_min = b_min; st.pmember_max = pm_max;
+    st.narrow_possible = ok && bg != BG_NONE && (int64_t)st.narrow_exceptions.size() * 8 <= n;
+    if (!st.narrow_possible) std::vector<int64_t>().swap(st.narrow_exceptions);
     return st;
 }
 
@@ -153,28 +166,27 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
     return true;
 }
 
-// Launch level for mcd::LaunchShape::fast: 0 plain kernels, 1 fast formulation, 2 narrow-range variant.
-// BGFIXED (BgFixedAcc::add<.., NARROW>): additionally pmember < 1 for every star (so every mixture value y >= 1 - p >= 2^-53),
-// lnlike_bg >= -150 and norm >= 2^-60 (so y <= 1 + 2 norm^-1/2 e^150 < 2^250): four raw factors fit between rescales;
-// and |v - v_los|^2 <= 1e7 norm.  BGGAUSS / PROFILE_BGGAUSS (BgGaussAcc::add<.., NARROW>): see below.
+// Launch level for mcd::LaunchShape::fast: 0 plain kernels, 1 fast formulation, 2 narrow-range variant (chunks that hold
+// a narrow_exception star still run the fast formulation of level 1).
+// BGFIXED (BgFixedAcc::add<.., NARROW>): pmember < 1 (so every mixture value y >= 1 - p >= 2^-53), lnlike_bg >= -150 and
+// norm >= 2^-60 (so y <= 1 + 2 norm^-1/2 e^150 < 2^250): four raw factors fit between rescales; |v - v_los|^2 <= 1e7 norm.
 inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
                       int64_t n_rows) {
     GuardRanges g;
     if (!fast_guard(st, model, free_centre, f32, k, params, n_rows, &g)) return 0;
     if (f32) return 1;
     const double lo = 0x1p-60, hi = 0x1p60;
-    // (d_max^2 <= 1e7 n_min: the exponent argument stays above -5e6, inside the int range of exp_tab without a clamp)
-    if (model == MODEL_BGFIXED && st.lnbg_min >= -150.0 && st.pmember_max < 1.0 && g.n_min >= lo &&
+    // Per-call conditions of the narrow-range variants (the per-star ones are CatalogStats::narrow_exceptions):
+    // d_max^2 <= 1e7 n_min keeps the exponent argument above -5e6, inside the int range of exp_tab without a clamp.
+    if (!st.narrow_possible) return 1;
+    if (model == MODEL_BGFIXED && g.n_min >= lo && g.d_max * g.d_max <= 1.0e7 * g.n_min) return 2;
+    // BgFixedAcc::add_density<NARROW>: y = f + rho g e^u >= f >= 2^-20 and <= 2^20 + 2^20 2^31 e^120 < 2^225
+    if (bg_kind(model) == BG_FIXED_DENSITY && g.f_min >= 0x1p-20 && g.f_max <= 0x1p20 && g.n_min >= lo &&
         g.d_max * g.d_max <= 1.0e7 * g.n_min)
         return 2;
-    // BgFixedAcc::add_density<NARROW>: y = f + rho g e^u >= f >= 2^-20 and <= 2^20 + 2^20 2^31 e^120 < 2^225
-    if (bg_kind(model) == BG_FIXED_DENSITY && st.lnbg_min >= -120.0 && st.rho_max <= 0x1p20 && g.f_min >= 0x1p-20 &&
-        g.f_max <= 0x1p20 && g.n_min >= lo && g.d_max * g.d_max <= 1.0e7 * g.n_min)
-        return 2;
     // BgGaussAcc::add<.., NARROW>: y >= the undamped term min(rho g, f g_b) >= 2^-20 2^-31 and y <= (rho + f) 2^31 <= 2^52
-    if (bg_kind(model) == BG_GAUSS && st.rho_min >= 0x1p-20 && st.rho_max <= 0x1p20 && g.f_min >= 0x1p-20 &&
-        g.f_max <= 0x1p20 && g.n_min >= lo && g.n_max <= hi && g.nb_min >= lo && g.nb_max <= hi &&
-        g.d_max * g.d_max <= 1.0e7 * std::min(g.n_min, g.nb_min))
+    if (bg_kind(model) == BG_GAUSS && g.f_min >= 0x1p-20 && g.f_max <= 0x1p20 && g.n_min >= lo && g.n_max <= hi &&
+        g.nb_min >= lo && g.nb_max <= hi && g.d_max * g.d_max <= 1.0e7 * std::min(g.n_min, g.nb_min))
         return 2;
     return 1;
 }

@@ -22,6 +22,8 @@ struct LaunchShape {
     int fast;         // 0 plain; 1 product/fraction-tree path (range guard passed); 2 narrow-range BGFIXED variant
     int uniform_len = 0;     // > 0: chunk c covers records [c * len, min((c + 1) * len, n_records)) of parameter set 0
     int64_t n_records = 0;
+    const uint8_t* chunk_general = nullptr;   // fast == 2: chunks that must take the general fast form (hold a star that
+                                              // rules out the narrow-range variant, mcd_guard.h: narrow_exception); may be null
     double* rerun_flag = nullptr;   // device word the fast mixture kernels set to `launch_tag` in the denormal regime
     double launch_tag = 0.0;
 };

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
                                                           double* __restrict__ partials, int64_t n_tasks,
                                                           int n_wtiles, int64_t n_walkers, int64_t n_chunks,
                                                           int uniform_len, int64_t n_records,
-                                                          double* __restrict__ rerun_flag, double launch_tag) {
+                                                          double* __restrict__ rerun_flag, double launch_tag,
+                                                          const uint8_t* __restrict__ chunk_general) {
     constexpr int ND = record_doubles(MODEL, FREE);
     // fast mixtures: the 2^(j/256) table of exp_tab lives in LDS (2 KiB), one entry copied per thread
     constexpr bool kUsesExpTab = FAST && bg_kind(MODEL) != BG_NONE && sizeof(T) == 8;
@@ -180,7 +181,16 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
 
     // wave-uniform record pointer: the reads inside chunk_loglike become scalar loads
     bool denormal;
-    const double result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
+    double result;
+    if constexpr (FAST == 2) {
+        // a chunk that holds a star outside the narrow-range domain (certain member, extreme background, ...) takes the
+        // general fast form; the flag is wave-uniform (one scalar byte load), so this is a scalar branch
+        const bool general = chunk_general != nullptr && chunk_general[chunk_id] != 0;
+        if (general) result = chunk_loglike<MODEL, FREE, T, A, 1>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
+        else result = chunk_loglike<MODEL, FREE, T, A, 2>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
+    } else {
+        result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
+    }
     // denormal regime of the reference's log-sum-exp met: tell the host to re-evaluate this batch with the plain kernels
     if (FAST && denormal && active) *rerun_flag = launch_tag;
     if (active) partials[w_raw * n_chunks + chunk_id] = result;
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void per_star_kernel(const T* __restrict__ 
 template <int MODEL, bool FREE, class T, class A, int FAST>
 hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, int64_t n_chunks, const void* wpar,
                       double* partials, int64_t n_walkers, int uniform_len, int64_t n_records, double* rerun_flag,
-                      double launch_tag) {
+                      double launch_tag, const uint8_t* chunk_general) {
     const int n_wtiles = (int)((n_walkers + kWave - 1) / kWave);
     const int64_t n_tasks = n_chunks * n_wtiles;
     int64_t grid = (n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -264,7 +274,7 @@ hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, i
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST>), dim3((unsigned)grid), dim3(kBlock), 0, s,
                        (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,
-                       uniform_len, n_records, rerun_flag, launch_tag);
+                       uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
     return hipGetLastError();
 }
 
@@ -275,27 +285,28 @@ hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* re
     const int64_t n_records = sh.n_records;
     double* const rerun_flag = sh.rerun_flag;
     const double launch_tag = sh.launch_tag;
+    const uint8_t* const chunk_general = sh.chunk_general;
     switch (sh.precision) {
         case 0:
             if constexpr (bg_kind(MODEL) != BG_NONE) {
                 if (sh.fast == 2)
                     return launch_one<MODEL, FREE, double, double, 2>(s, records, chunks, n_chunks, wpar, partials,
-                                                                      n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+                                                                      n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
             }
             if (sh.fast)
                 return launch_one<MODEL, FREE, double, double, 1>(s, records, chunks, n_chunks, wpar, partials,
-                                                                  n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
-            return launch_one<MODEL, FREE, double, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+                                                                  n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+            return launch_one<MODEL, FREE, double, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
         case 1:
             if (sh.fast && bg_kind(MODEL) == BG_NONE)
                 return launch_one<MODEL, FREE, float, float, bg_kind(MODEL) == BG_NONE ? 1 : 0>(s, records, chunks, n_chunks, wpar,
-                                                                                       partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
-            return launch_one<MODEL, FREE, float, float, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+                                                                                       partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+            return launch_one<MODEL, FREE, float, float, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
         case 2:
             if (sh.fast && bg_kind(MODEL) == BG_NONE)
                 return launch_one<MODEL, FREE, float, double, bg_kind(MODEL) == BG_NONE ? 1 : 0>(s, records, chunks, n_chunks, wpar,
-                                                                                        partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
-            return launch_one<MODEL, FREE, float, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag);
+                                                                                        partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+            return launch_one<MODEL, FREE, float, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
     }
     return hipErrorInvalidValue;
 }

@@ -23,7 +23,24 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
         for (int64_t s = 0; s < n; s += chunk_len) {
             const int count = (int)((n - s) < chunk_len ? (n - s) : chunk_len);
             bool denormal;
-            total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c, denormal, exp_table_is_sqrt2_scaled(MODEL) ? kExpTabSqrt2Host : kExpTabHost);
+            const double* tab = exp_table_is_sqrt2_scaled(MODEL) ? kExpTabSqrt2Host : kExpTabHost;
+            if constexpr (FAST == 2) {
+                // the library's per-chunk choice (build_workset + loglike_kernel): a chunk holding a narrow_exception star
+                // takes the general fast form
+                constexpr int XB = geometry_doubles(MODEL, FREE);
+                constexpr int BG = bg_kind(MODEL);
+                bool general = false;
+                for (int64_t i = s; i < s + count && !general; ++i) {
+                    const double* r = recs + i * ND;
+                    general = BG == BG_FIXED ? narrow_exception(BG, r[XB], r[XB + 1], 1.0)
+                            : BG == BG_GAUSS ? narrow_exception(BG, 0.0, 0.0, r[XB])
+                                             : narrow_exception(BG, r[XB], 0.0, r[XB + 2]);
+                }
+                total += general ? chunk_loglike<MODEL, FREE, double, double, 1>(recs + s * ND, count, c, denormal, tab)
+                                 : chunk_loglike<MODEL, FREE, double, double, 2>(recs + s * ND, count, c, denormal, tab);
+            } else {
+                total += chunk_loglike<MODEL, FREE, double, double, FAST>(recs + s * ND, count, c, denormal, tab);
+            }
             rerun = rerun || denormal;
         }
         if (FAST && rerun) {                          // what the library does: the batch is re-evaluated with the plain kernels

@@ -184,24 +184,35 @@ def test_narrow_range_bgfixed_variant_matches_reference(which, chunk_len):
 
 
 def test_narrow_range_level_conditions():
-    """fast_level drops from 2 to 1 as soon as one condition of the narrow variant fails: a certain member
-    (pmember == 1: the mixture value can underflow) or a background likelihood below e^-150 (the value can exceed
-    2^250); and the narrow variant agrees with the wide one at the edges of its domain."""
+    """A star that falls outside the domain of the narrow-range variant -- a certain member (pmember == 1: the mixture
+    value has no floor) or a background likelihood below e^-150 (the value can exceed 2^250) -- only sends ITS CHUNK to
+    the general fast form (level stays 2, results agree with the plain path); once more than 1/8 of the stars are such
+    exceptions the whole launch uses the general form (level 1).  The narrow variant agrees with the wide one at the edges
+    of its domain."""
     g = load_golden("constant_bg_gaussian_fixed")
     centre = (float(g["ra_center"]), float(g["dec_center"]))
     rows = g["values"][np.isfinite(g["lnprior"]) & (g["values"][:, 1] > 0)]
     base = {k: g[k].copy() for k in ("ra", "dec", "v", "verr", "pmember")}
     base["lnlike_bg"] = g["lnlike_background"].copy()
     assert emul.fast_level(base, rows, 1, centre) == 2
-    cat = dict(base, pmember=base["pmember"].copy())
-    cat["pmember"][5] = 1.0
-    assert emul.fast_level(cat, rows, 1, centre) == 1
-    cat = dict(base, lnlike_bg=base["lnlike_bg"].copy())
-    cat["lnlike_bg"][5] = -151.0
-    assert emul.fast_level(cat, rows, 1, centre) == 1
-    # (the third condition, norm >= 2^-60, only binds for velocity scales below 1e-9 km/s: the level-1 guard
+    n = len(base["v"])
+    for field, value, outlier in (("pmember", 1.0, 400.0), ("lnlike_bg", -151.0, None), ("lnlike_bg", -5000.0, None)):
+        cat = {k: v.copy() for k, v in base.items()}
+        cat[field][[5, 700, n - 1]] = value
+        if outlier is not None:
+            cat["v"][5] = outlier                      # a certain member 40 sigma out: y ~ e^-800, far below 2^-250
+        assert emul.fast_level(cat, rows, 1, centre) == 2
+        plain = emul.loglike(cat, rows, 1, centre, 0, 64)
+        mixed = emul.loglike(cat, rows, 1, centre, 2, 64)   # chunks of 64 stars: three of them take the general form
+        assert np.array_equal(np.isfinite(plain), np.isfinite(mixed))
+        ok = np.isfinite(plain)
+        assert rel_err(mixed[ok], plain[ok]) < RTOL
+    many = {k: v.copy() for k, v in base.items()}
+    many["pmember"][: n // 8 + 1] = 1.0
+    assert emul.fast_level(many, rows, 1, centre) == 1
+    # (the per-call condition norm >= 2^-60 only binds for velocity scales below 1e-9 km/s: the level-1 guard
     #  |v - v_los|^2 <= 1.6e9 norm is stricter for anything larger)
-    assert emul.fast_level(base, rows, 0, centre) == 1              # other models have no narrow variant
+    assert emul.fast_level(base, rows, 0, centre) == 1              # models without background have no narrow variant
     # edges of the domain: lnL_bg = -150 on a star the cluster model loves (largest y), pmember = 1 - 2^-53 (smallest y)
     # on 80-sigma outliers, four of them in a row so that they share one rescale group
     edge = {k: v.copy() for k, v in base.items()}
@@ -238,8 +249,10 @@ def test_narrow_range_gaussian_background_variant_matches_reference(name, model,
     zero_f[0, -1] = 0.0                                    # f_back = 0: the undamped term can vanish -> general form
     assert emul.fast_level(cat, zero_f, model, centre) == 1
     sparse = dict(cat, density=cat["density"].copy())
-    sparse["density"][7] = 0.0
-    assert emul.fast_level(sparse, values, model, centre) == 1
+    sparse["density"][[7, 333]] = 0.0                      # empty cluster component on two stars: their chunks go general
+    assert emul.fast_level(sparse, values, model, centre) == 2
+    plain = emul.loglike(sparse, values, model, centre, 0, 64)
+    assert rel_err(emul.loglike(sparse, values, model, centre, 2, 64), plain) < RTOL
 
 
 @pytest.mark.parametrize("which", ["fixed", "free"])
