@@ -194,8 +194,9 @@ int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_lau
  * f_back == 0 or density == 0 that lies > 37 sigma from the only remaining component.  Only the literal expression
  * reproduces the reference's value there; the re-evaluation is automatic and synchronous inside fetch / batch. */
 int64_t mcd_rerun_count(const mcd_catalog* cat);
-/* Kernel family the range guard chose for the batch staged last: 0 plain, 1 fast formulation, 2 narrow-range
- * fixed-background variant (every pmember < 1, lnlike_bg >= -150: no per-star exponent bookkeeping); -1 before any call. */
+/* Kernel family the range guard chose for the batch staged last: 0 plain, 1 fast formulation, 2 narrow-range variant of
+ * the mixture kernels (no per-star exponent bookkeeping; chunks holding a star outside its domain -- a certain member, an
+ * extreme background likelihood, an empty component -- still run the fast formulation); -1 before any call. */
 int mcd_last_fast_level(const mcd_catalog* cat);
 /* Launch geometry of the main kernel for the last call: workgroups, walker tile (walkers that
  * reuse one star record load), chunks per parameter set, bytes per star record. */
