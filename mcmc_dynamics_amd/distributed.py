@@ -39,6 +39,28 @@ def shard_bin_offsets(bin_offsets, rank, world):
     return np.clip(offs, lo, hi) - lo
 
 
+def replicated_loglike(loglike_fn, params, rank=None, world=None, process_group=None):
+    """The other axis ("replicas"): every rank holds the FULL catalogue and evaluates only its
+    contiguous slice of the walkers; the slices are exchanged over the host process group (no device collective).  For
+    catalogues too small to fill several GPUs.  ``loglike_fn((w, K)) -> (w,)``; returns the complete ``(W,)`` on every rank."""
+    import torch
+    import torch.distributed as dist
+    if rank is None or world is None:
+        rank, world, _ = env_rank()
+    params = np.asarray(params, dtype=np.float64)
+    lo, hi = shard_bounds(len(params), rank, world)
+    mine = np.asarray(loglike_fn(params[lo:hi]), dtype=np.float64) if hi > lo else np.empty(0)
+    if world == 1:
+        return mine
+    sizes = [shard_bounds(len(params), r, world) for r in range(world)]
+    width = max(h - l for l, h in sizes)
+    padded = torch.zeros(width, dtype=torch.float64)
+    padded[:hi - lo] = torch.from_numpy(mine)
+    parts = [torch.zeros(width, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(parts, padded, group=process_group)
+    return np.concatenate([parts[r][:h - l].numpy() for r, (l, h) in enumerate(sizes)])
+
+
 def env_rank():
     """(rank, world, local_rank) from the torchrun environment (defaults: single process)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),

@@ -43,6 +43,12 @@ def main():
     err = np.max(np.abs(partial.numpy() - want) / np.abs(want))
     assert err < 1e-13, err
 
+    # the other axis: full catalogue on every rank, walkers split across ranks, slices gathered over the host group
+    many = synthetic.make_walkers(13, names, full["truth"], config=4)          # odd count: uneven slices
+    got = distributed.replicated_loglike(lambda p: oracle.batched_constant_lnlike(full, p, *centre), many, rank, world)
+    ref = oracle.batched_constant_lnlike(full, many, *centre)
+    assert got.shape == (13,) and np.array_equal(got, ref)
+
     # binned catalogue: bins that straddle the shard boundary contribute partial sums from both ranks
     dx, dy = oracle.calc_xy_offset(full["ra"], full["dec"], *centre)
     bins = oracle.make_radial_bins(np.hypot(dx, dy), 300, 0.05).astype(np.int64)
