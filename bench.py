@@ -31,7 +31,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, c
 #   slots per term of the fast-path inner loops from the gfx950 ISA (tools/isa_mix.py; bgfixed / bggauss = the narrow-range variants
 #   the guard selects for the bench catalogue), one slot = one f64 wave-instruction
 #   per SIMD = 2.33 ns on the fully occupied chip (tools/valu_rate_probe.hip).
-VALU_SLOTS_PER_TERM = {"const": 9.11, "bgfixed": 26.65, "bggauss": 49.55, "profile": 27.91}
+VALU_SLOTS_PER_TERM = {"const": 8.56, "bgfixed": 26.65, "bggauss": 49.55, "profile": 27.91}
 VALU_SLOT_NS = 2.33
 COLLECTIVE_TIMEOUT_S = 180
 N_SIMD = 256 * 4

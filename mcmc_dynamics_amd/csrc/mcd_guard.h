@@ -83,7 +83,7 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
 }
 
 // Fast paths (f64 only) are valid while their intermediate products stay far from over/underflow.
-//   CONST   (fraction tree over 8 stars + log product): 2^-60 <= verr^2 + sigma^2 <= 2^60, |v - v_los| < 2^58
+//   CONST   (fraction tree over 8 / 16 stars + log product): 2^-55 <= verr^2 + sigma^2 <= 2^55, |v - v_los| < 2^50
 //   BGFIXED / BGGAUSS (rsqrt + one exp + log product):  2^-200 <= norm <= 2^200, |v - v_los|^2 / norm <= 1.6e9, finite columns,
 //            lnlike_bg > -1e5, 0 <= pmember <= 1 (>= 2^-700 where lnlike_bg < -690);  density >= 0 (likewise), f_back >= 0, 2^-100 <= density + f_back <= 2^100
 // Anything else (including NaN/inf parameters) takes the plain kernels, which evaluate the reference's
@@ -150,7 +150,8 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
         if (f32)      // 4-star tree in f32: DEN <= 2^60, NUM <= 2^77
             return (n_min >= std::ldexp(1.0, -15)) && (n_max <= std::ldexp(1.0, 15)) && (d_max <= std::ldexp(1.0, 15)) &&
                    (!prof || (len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20)));
-        return (n_min >= std::ldexp(1.0, -60)) && (n_max <= std::ldexp(1.0, 60));
+        // 16-star tree of MODEL_CONST: DEN = prod of 16 norms within 2^+-880, NUM <= q norm^15 <= 2^100 2^825
+        return (n_min >= std::ldexp(1.0, -55)) && (n_max <= std::ldexp(1.0, 55)) && (d_max <= std::ldexp(1.0, 50));
     }
     const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
     if (!((n_min >= lo) && (n_max <= hi))) return false;

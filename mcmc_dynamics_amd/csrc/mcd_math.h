@@ -262,6 +262,17 @@ struct ConstAcc {          // accumulators of one walker over one chunk (MODEL_C
         l.mul(f.den);
         l.rescale();
     }
+    // 16 stars: one more level of the tree, still ONE reciprocal (DEN = prod of 16 norms needs |log2 norm| <= 50)
+    MCD_HD void add16(const double* qq, const double* nn) {
+        Frac a = frac_join(frac_join(frac_leaf2(qq[0], nn[0], qq[1], nn[1]), frac_leaf2(qq[2], nn[2], qq[3], nn[3])),
+                           frac_join(frac_leaf2(qq[4], nn[4], qq[5], nn[5]), frac_leaf2(qq[6], nn[6], qq[7], nn[7])));
+        Frac b = frac_join(frac_join(frac_leaf2(qq[8], nn[8], qq[9], nn[9]), frac_leaf2(qq[10], nn[10], qq[11], nn[11])),
+                           frac_join(frac_leaf2(qq[12], nn[12], qq[13], nn[13]), frac_leaf2(qq[14], nn[14], qq[15], nn[15])));
+        Frac f = frac_join(a, b);
+        q += f.num * rcp_nr(f.den);
+        l.mul(f.den);
+        l.rescale();
+    }
     MCD_HD void add1(double q1, double n1) {
         q += q1 / n1;
         l.mul_any(n1);
@@ -665,7 +676,10 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         // less than one load latency even with 8 waves per SIMD.
         ConstAccF<A> acc;
         acc.init();
-        const int n16 = count >> 4;
+        // MODEL_CONST with a fixed centre has registers to spare for a 16-star tree (one reciprocal per 16 stars); the
+        // other instantiations keep 8-star trees (a 16-star tree there costs occupancy)
+        constexpr bool TREE16 = MODEL == MODEL_CONST && !FREE;
+        const int n16 = TREE16 ? count >> 4 : 0;
         for (int g = 0; g < n16; ++g, r += 16 * ND) {
             float qq[16], nn[16];
 #pragma unroll
@@ -699,7 +713,21 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         // fraction-tree + log-product path (f64): 8 stars -> one division, one product factor
         ConstAcc acc;
         acc.init();
-        const int n8 = count >> 3;
+        // MODEL_CONST with a fixed centre has registers to spare for a 16-star tree (one reciprocal per 16 stars); the
+        // other instantiations keep 8-star trees (a 16-star tree there costs occupancy)
+        constexpr bool TREE16 = MODEL == MODEL_CONST && !FREE;
+        const int n16 = TREE16 ? count >> 4 : 0;
+        for (int g = 0; g < n16; ++g, r += 16 * ND) {
+            double qq[16], nn[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double d;
+                star_d_n<MODEL, double, FREE, true>(r + j * ND, w, d, nn[j]);
+                qq[j] = d * d;
+            }
+            acc.add16(qq, nn);
+        }
+        const int n8 = TREE16 ? (count >> 3) & 1 : count >> 3;
         for (int g = 0; g < n8; ++g, r += 8 * ND) {
             double qq[8], nn[8];
 #pragma unroll
@@ -710,7 +738,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             }
             acc.add8(qq, nn);
         }
-        for (int j = n8 * 8; j < count; ++j, r += ND) {
+        for (int j = count & ~7; j < count; ++j, r += ND) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
             acc.add1(d * d, n);

@@ -20,7 +20,7 @@ CSRC = os.path.join(ROOT, "mcmc_dynamics_amd", "csrc")
 SLOT_NS = 2.33
 
 KERNELS = [  # (template tag, name, stars per loop iteration)
-    ("ILi0ELb0EddLi1E", "CONST fixed centre", 8), ("ILi0ELb1EddLi1E", "CONST free centre", 8),
+    ("ILi0ELb0EddLi1E", "CONST fixed centre", 16), ("ILi0ELb1EddLi1E", "CONST free centre", 8),
     ("ILi1ELb0EddLi1E", "BGFIXED fixed centre", 4), ("ILi1ELb0EddLi2E", "BGFIXED fixed, narrow", 4), ("ILi2ELb0EddLi1E", "BGGAUSS fixed centre", 4),
     ("ILi2ELb0EddLi2E", "BGGAUSS fixed, narrow", 4),
     ("ILi3ELb0EddLi1E", "PROFILE fixed centre", 8), ("ILi4ELb0EddLi1E", "PROFILE_BGGAUSS fixed", 4),
