@@ -347,6 +347,45 @@ def test_rccl_call_path_on_one_rank(native):
     ctx1.close()
 
 
+def test_pipelined_enqueue_never_mixes_steps(native, ctx):
+    """mcd_params_upload / mcd_loglike_enqueue / mcd_loglike_fetch with DIFFERENT walker tables per step, different
+    pipeline depths and blocking calls in between: every fetched result equals the blocking call's, bit for bit."""
+    from mcmc_dynamics_amd import synthetic
+    c, centre = _synthetic(60000, 3, background=True)
+    names = NAMES4
+    lnbg = synthetic_gaussian_background(c)
+    cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST_BGFIXED, centre=centre,
+                         lnlike_bg=lnbg, pmember=c["pmember"])
+    ref = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST_BGFIXED, centre=centre,
+                         lnlike_bg=lnbg, pmember=c["pmember"])
+    rng = np.random.default_rng(12)
+    base = synthetic.make_walkers(192, names, c["truth"], config=3)
+    for depth in (1, 2, 3, 4, 9):
+        tables = [base * (1.0 + 0.02 * rng.normal(size=base.shape)) for _ in range(depth)]
+        want = [ref.loglike(t) for t in tables]
+        for t in tables:                                   # only the last result is fetched ...
+            cat.upload_params(t)
+            cat.enqueue()
+        assert np.array_equal(cat.fetch(), want[-1])
+        for t, w in zip(tables, want):                     # ... and every one when fetched step by step
+            cat.upload_params(t)
+            cat.enqueue()
+            assert np.array_equal(cat.fetch(), w)
+        cat.upload_params(tables[0])
+        for _ in range(depth + 1):
+            cat.enqueue()
+        assert np.array_equal(cat.loglike(tables[-1]), want[-1])      # blocking call right behind pipelined steps
+        cat.enqueue()                                                # pipelined step right behind a blocking call
+        assert np.array_equal(cat.fetch(), want[-1])
+    cat.close()
+    ref.close()
+
+
+def synthetic_gaussian_background(c):
+    from mcmc_dynamics_amd.background import Gaussian
+    return Gaussian(20.0, 40.0)(c["v"], c["verr"])
+
+
 def test_c4_size_shards(native, ctx):
     """1e7 stars x 256 walkers (C4): the eight 1.25e6-star shards a node would hold sum to the un-sharded value
     (what the RCCL all-reduce computes), and the sum over radial bins equals it too."""

@@ -16,11 +16,11 @@ cats = {"const": _native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], mode
 ref = {k: g.loglike(pos) for k, g in cats.items()}
 for rep in range(1):
     for name, g in cats.items():
-        for tw in (8192, 12288, 16384):
+        for tw in (6144, 8192, 12288, 16384, 24576):
             for split in (0, 1, 2):
                 g.set_option("target_waves", tw); g.set_option("tail_split", split); g.set_option("timing", 2)
                 g.upload_params(pos)
-                for _ in range(30): g.enqueue()
+                for _ in range(800): g.enqueue()
                 g.sync(); g.timing_collect()
                 t0 = time.perf_counter()
                 for _ in range(300): g.enqueue()
