@@ -172,6 +172,8 @@ double mcd_last_device_ms(const mcd_catalog* cat);
 /* Tuning / measurement switches, per catalogue.  Keys:
  *   "timing"        1: record HIP events around every enqueue (default 0); 2: additionally keep one
  *                      event pair per main-kernel launch for mcd_timing_collect
+ *   "timing_stride" n: with "timing" = 2, record the event pair on every n-th launch only (default 1); the events cost a
+ *                      signal packet each between back-to-back kernels, so a throughput harness samples
  *   "timing_reserve" n: create the event pairs for n launches of "timing" = 2 now, so that a measured loop does not
  *                      pay for hipEventCreate
  *   "fast_path"     0: always use the plain per-term log/divide kernels; 1 (default): the fast formulations

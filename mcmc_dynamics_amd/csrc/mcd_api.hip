@@ -158,6 +158,8 @@ struct mcd_catalog {
     bool timing_all = false;           // keep an event pair for every launch (measurement harness)
     int allow_fast = 1;                // option "fast_path": 0 plain kernels only, 1 guard decides, 2 guard decides but never the narrow variant
     bool zero_copy = true;             // blocking call reads params / writes results through mapped pinned memory
+    int64_t timing_stride = 1;         // "timing" = 2: event pair on every n-th launch only (option "timing_stride")
+    int64_t timing_launches = 0;
     int tail_split = 1;                // guided chunk schedule (shorter chunks at the end of a launch)
     int64_t target_waves = 12288;
     // state of the last evaluation
@@ -395,7 +397,9 @@ int enqueue(mcd_catalog* cat) {
         }
         shape.launch_tag = w.launch_tag;
         hipEvent_t k0 = sh.ev_k0, k1 = sh.ev_k1;
-        if (cat->timing_all) {
+        // per-launch events cost a signal packet each (~3 us per pair between back-to-back kernels): a harness may sample
+        const bool sampled = !cat->timing_all || (cat->timing_launches % cat->timing_stride) == 0;
+        if (cat->timing_all && sampled) {
             if (sh.ring_used >= (size_t)1 << 16) sh.ring_used = 0;        // harness option left on: recycle, never grow without bound
             if (sh.ring_used == sh.ring.size()) {
                 hipEvent_t a, b;
@@ -408,9 +412,9 @@ int enqueue(mcd_catalog* cat) {
             ++sh.ring_used;
         }
         if (cat->timing && !cat->timing_all) MCD_HIP(hipEventRecord(sh.ev_begin, slot.stream));
-        if (cat->timing) MCD_HIP(hipEventRecord(k0, slot.stream));
+        if (cat->timing && sampled) MCD_HIP(hipEventRecord(k0, slot.stream));
         MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, W));
-        if (cat->timing) MCD_HIP(hipEventRecord(k1, slot.stream));
+        if (cat->timing && sampled) MCD_HIP(hipEventRecord(k1, slot.stream));
         // the fast BGFIXED kernel leaves the walker-independent sum of lnL_bg to the reduction
         const int bgk = mcd::bg_kind(cat->model);
         const double* pset_const =
@@ -440,6 +444,7 @@ int enqueue(mcd_catalog* cat) {
             w.comm_pending[w.buf] = true;
         }
     }
+    if (cat->timing_all) ++cat->timing_launches;
     if (cat->timing) {
         if (!cat->timing_all) {
             for (Shard& sh : cat->shards) {
@@ -470,10 +475,12 @@ int sync_all(mcd_catalog* cat) {
     if (cat->timing && cat->timing_pending) {
         Shard& sh = cat->shards[0];
         float k_ms = 0.f, d_ms = 0.f;
-        if (cat->timing_all && sh.ring_used > 0)
-            MCD_HIP(hipEventElapsedTime(&k_ms, sh.ring[sh.ring_used - 1].first, sh.ring[sh.ring_used - 1].second));
-        else
+        if (cat->timing_all) {
+            if (sh.ring_used > 0)          // (none yet when only unsampled launches ran since the last collect)
+                MCD_HIP(hipEventElapsedTime(&k_ms, sh.ring[sh.ring_used - 1].first, sh.ring[sh.ring_used - 1].second));
+        } else {
             MCD_HIP(hipEventElapsedTime(&k_ms, sh.ev_k0, sh.ev_k1));
+        }
         if (!cat->timing_all) MCD_HIP(hipEventElapsedTime(&d_ms, sh.ev_begin, sh.ev_end));
         cat->last_kernel_ms = k_ms;
         cat->last_device_ms = cat->timing_all ? -1.0 : d_ms;
@@ -894,6 +901,14 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         for (Shard& sh : cat->shards) sh.ring_used = 0;
         return MCD_OK;
     }
+    if (!std::strcmp(key, "timing_stride")) {
+        if (value < 1) return fail(MCD_ERR_INVALID, "timing_stride must be >= 1");
+        int rc = sync_all(cat);
+        if (rc != MCD_OK) return rc;
+        cat->timing_stride = value;
+        cat->timing_launches = 0;
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "timing_reserve")) {
         // create the per-launch event pairs of "timing" = 2 ahead of a measured loop (hipEventCreate costs microseconds)
         if (value < 0 || value > ((int64_t)1 << 16)) return fail(MCD_ERR_INVALID, "timing_reserve: 0 .. 65536 launches");
@@ -946,6 +961,7 @@ int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_lau
     if (total_kernel_ms) *total_kernel_ms = total;
     if (n_launches) *n_launches = (int64_t)sh.ring_used;
     for (Shard& s2 : cat->shards) s2.ring_used = 0;
+    cat->timing_launches = 0;                  // the first launch after a collect is sampled
     return MCD_OK;
 }
 
