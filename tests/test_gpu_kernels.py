@@ -129,6 +129,22 @@ def test_abi_errors(native, ctx):
         native.Catalog(ctx, g["ra"], g["dec"], g["v"], g["verr"], model=native.MODEL_CONST_BGGAUSS, centre=None)
     empty = native.Catalog(ctx, [], [], [], [], model=native.MODEL_CONST, centre=(0.0, 0.0))
     assert np.array_equal(empty.loglike(g["values"]), np.zeros(len(g["values"])))
+    # call-order and option misuse: status codes with a message, never a crash
+    fresh = native.Catalog(ctx, g["ra"], g["dec"], g["v"], g["verr"], model=native.MODEL_CONST,
+                           centre=(float(g["ra_center"]), float(g["dec_center"])))
+    assert fresh.fast_level == -1
+    with pytest.raises(native.NativeError, match="staged|evaluated"):
+        fresh.enqueue()
+    for key, bad in (("fast_path", 3), ("fast_path", -1), ("timing_stride", 0), ("timing_reserve", -5),
+                     ("target_waves", 0), ("no_such_option", 1)):
+        with pytest.raises(native.NativeError):
+            fresh.set_option(key, bad)
+    with pytest.raises(native.NativeError):
+        fresh.membership(g["values"][0])                 # membership needs a background model
+    assert np.all(np.isfinite(fresh.loglike(g["values"][np.isfinite(g["lnprior"])])))   # still usable afterwards
+    fresh.close()
+    with pytest.raises(native.NativeError):
+        fresh.loglike(g["values"])                       # closed catalogue
 
 
 # ------------------------------------------------------------------------------------------------
