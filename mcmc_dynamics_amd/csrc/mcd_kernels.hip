@@ -213,8 +213,17 @@ __global__ __launch_bounds__(kBlock) void reduce_wide_kernel(const double* __res
     const int64_t pset = o / n_walkers, w = o - pset * n_walkers;
     const int64_t c0 = offs[pset], c1 = offs[pset + 1];
     const double* __restrict__ row = partials + w * n_chunks;
-    double acc = 0.0;
-    for (int64_t c = c0 + threadIdx.x; c < c1; c += kBlock) acc += row[c];
+    // four independent accumulators per thread keep four loads in flight (fixed order: bitwise repeatable)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t c = c0 + threadIdx.x;
+    for (; c + 3 * kBlock < c1; c += 4 * kBlock) {
+        a0 += row[c];
+        a1 += row[c + kBlock];
+        a2 += row[c + 2 * kBlock];
+        a3 += row[c + 3 * kBlock];
+    }
+    for (; c < c1; c += kBlock) a0 += row[c];
+    double acc = (a0 + a1) + (a2 + a3);
     acc = wave_sum(acc);
     if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
