@@ -370,9 +370,9 @@ int enqueue(mcd_catalog* cat) {
         const DeviceSlot& slot = ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast, w.uniform_len, sh.n};
-        // Re-run flag word behind the outputs.  One device: a fresh tag per launch, no reset needed.  Several ranks /
-        // devices: the word is zeroed, kernels write 1, and the word rides along in the all-reduce (count n_out + 1),
-        // so that every rank sees the same sum and takes the same decision.
+        // Re-run signal of the fast mixture kernels.  One device: a flag word behind the outputs receives a fresh tag per
+        // launch (no reset needed).  Several ranks / devices: the kernels poison the affected partial sums with NaN
+        // instead, which travels through the reduce kernel and the all-reduce to every rank.
         const bool coll = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
         double* out_buf = w.mapped ? w.m_out : w.d_out;
         if (coll) {
@@ -388,13 +388,8 @@ int enqueue(mcd_catalog* cat) {
             w.buf = 0;
         }
         shape.chunk_general = w.d_chunk_general;
-        shape.rerun_flag = out_buf + n_out;
-        if (coll) {
-            w.launch_tag = 1.0;
-            MCD_HIP(hipMemsetAsync(shape.rerun_flag, 0, sizeof(double), slot.stream));
-        } else {
-            w.launch_tag = (double)(++cat->launch_seq);
-        }
+        shape.rerun_flag = coll ? nullptr : out_buf + n_out;
+        w.launch_tag = coll ? 0.0 : (double)(++cat->launch_seq);
         shape.launch_tag = w.launch_tag;
         hipEvent_t k0 = sh.ev_k0, k1 = sh.ev_k1;
         // per-launch events cost a signal packet each (~3 us per pair between back-to-back kernels): a harness may sample
@@ -433,7 +428,7 @@ int enqueue(mcd_catalog* cat) {
             MCD_HIP(hipSetDevice(slot.device));
             double* buf = w.buf ? w.d_out2 : w.d_out;
             MCD_HIP(hipStreamWaitEvent(slot.comm_stream, w.ev_reduced[w.buf], 0));
-            MCD_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n_out + 1, ncclDouble, ncclSum, slot.comm, slot.comm_stream));
+            MCD_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n_out, ncclDouble, ncclSum, slot.comm, slot.comm_stream));
         }
         if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
         for (Shard& sh : cat->shards) {
@@ -493,29 +488,29 @@ int fetch_once(mcd_catalog* cat, bool* rerun) {
     const int64_t W = cat->cur_walkers;
     const int64_t n_out = cat->n_psets * W;
     *rerun = false;
-    // every shard keeps its own flag word behind its outputs (all-reduced together with them in collective mode)
+    const bool coll = cat->ctx->n_ranks > 1 || cat->ctx->slots.size() > 1 || cat->ctx->force_collective;
+    bool any_fast = false;
     for (Shard& sh : cat->shards) {
         WorkSet& w = sh.work.at(W);
+        any_fast = any_fast || w.fast != 0;
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
-        if (!w.mapped) {
-            const bool first = &sh == &cat->shards[0];
+        // after the all-reduce every device holds the same results: only the first shard's are copied
+        if (!w.mapped && &sh == &cat->shards[0]) {
             const double* res = w.buf ? w.d_out2 : w.d_out;
             if (w.comm_pending[w.buf]) MCD_HIP(hipStreamWaitEvent(slot.stream, w.ev_comm[w.buf], 0));
-            double* dst = first ? w.h_out : w.h_out + n_out;
-            const double* src = first ? res : res + n_out;
-            MCD_HIP(hipMemcpyAsync(dst, src, (size_t)(first ? n_out + 1 : 1) * sizeof(double), hipMemcpyDeviceToHost,
-                                   slot.stream));
+            MCD_HIP(hipMemcpyAsync(w.h_out, res, (size_t)(n_out + 1) * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
         }
     }
     int rc = sync_all(cat);
     if (rc != MCD_OK) return rc;
-    const bool coll = cat->ctx->n_ranks > 1 || cat->ctx->slots.size() > 1 || cat->ctx->force_collective;
-    for (Shard& sh : cat->shards) {
-        WorkSet& w = sh.work.at(W);
-        if (!w.fast) continue;
-        const double flag = w.h_out[n_out];
-        if (coll ? flag > 0.0 : flag == w.launch_tag) *rerun = true;
+    const WorkSet& w0 = cat->shards[0].work.at(W);
+    if (coll) {
+        // Every rank decides on the all-reduced values alone (identical everywhere), whatever kernel family it ran itself:
+        // the re-evaluation is collective.  (A NaN that the plain kernels produce legitimately costs one extra pass.)
+        for (int64_t i = 0; i < n_out && !*rerun; ++i) *rerun = w0.h_out[i] != w0.h_out[i];      // NaN-poisoned sums
+    } else if (any_fast) {
+        *rerun = w0.h_out[n_out] == w0.launch_tag;
     }
     return MCD_OK;
 }
@@ -532,8 +527,8 @@ int fetch(mcd_catalog* cat, double* out) {
         // A fast mixture kernel met the regime where the reference's log-sum-exp runs on denormal numbers (a star with
         // pmember == 1, f_back == 0 or density == 0 that is a > 37 sigma outlier of the remaining component).  Only the
         // plain kernels reproduce the reference's value there: evaluate the staged batch again with them.  In a
-        // multi-rank job every rank must take the same decision (the all-reduce is collective): ranks agree through
-        // the all-reduced flag below.
+        // multi-rank job every rank takes the same decision (the all-reduce is collective): the affected partial sums
+        // are NaN-poisoned by the kernel, so the all-reduced results carry the signal to every rank (fetch_once).
         ++cat->n_reruns;
         for (Shard& sh : cat->shards) sh.work.at(W).fast = 0;
         rc = enqueue(cat);

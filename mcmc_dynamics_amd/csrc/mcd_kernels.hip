@@ -192,7 +192,13 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
         result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
     }
     // denormal regime of the reference's log-sum-exp met: tell the host to re-evaluate this batch with the plain kernels
-    if (FAST && denormal && active) *rerun_flag = launch_tag;
+    // One device: the flag word gets this launch's tag.  Several ranks / devices (rerun_flag == nullptr): the partial sum
+    // itself becomes NaN, which survives the reduce kernel and the all-reduce, so every rank sees it in the same walkers
+    // and takes the same decision -- no flag word to zero before every launch.
+    if (FAST && denormal && active) {
+        if (rerun_flag) *rerun_flag = launch_tag;
+        else result = __builtin_nan("");
+    }
     if (active) partials[w_raw * n_chunks + chunk_id] = result;
 }
 
