@@ -358,7 +358,10 @@ int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* p
     return MCD_OK;
 }
 
-int enqueue(mcd_catalog* cat) {
+// pipelined (mcd_loglike_enqueue): the all-reduce goes to the communication stream and overlaps the next step's kernels.
+// A blocking call gains nothing from that hop: its all-reduce stays on the compute stream (after any collective still
+// pending on the communication stream, so that operations on one communicator never run concurrently).
+int enqueue(mcd_catalog* cat, bool pipelined) {
     if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
     if (cat->cur_walkers <= 0) return fail(MCD_ERR_INVALID, "no parameters staged (call mcd_params_upload first)");
     const int64_t W = cat->cur_walkers;
@@ -416,7 +419,7 @@ int enqueue(mcd_catalog* cat) {
             (w.fast && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
         MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, w.n_chunks,
                                    w.max_chunks_per_pset, W, pset_const, out_buf));
-        if (coll) MCD_HIP(hipEventRecord(w.ev_reduced[w.buf], slot.stream));
+        if (coll && pipelined) MCD_HIP(hipEventRecord(w.ev_reduced[w.buf], slot.stream));
     }
     // sum the per-device / per-rank partial log-likelihoods: one all-reduce of n_out doubles
     const bool collective = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
@@ -427,16 +430,26 @@ int enqueue(mcd_catalog* cat) {
             const DeviceSlot& slot = ctx->slots[sh.slot];
             MCD_HIP(hipSetDevice(slot.device));
             double* buf = w.buf ? w.d_out2 : w.d_out;
-            MCD_HIP(hipStreamWaitEvent(slot.comm_stream, w.ev_reduced[w.buf], 0));
-            MCD_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n_out, ncclDouble, ncclSum, slot.comm, slot.comm_stream));
+            if (pipelined) {
+                MCD_HIP(hipStreamWaitEvent(slot.comm_stream, w.ev_reduced[w.buf], 0));
+                MCD_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n_out, ncclDouble, ncclSum, slot.comm, slot.comm_stream));
+            } else {
+                if (w.comm_pending[w.buf ^ 1]) {           // the newest collective still on the communication stream
+                    MCD_HIP(hipStreamWaitEvent(slot.stream, w.ev_comm[w.buf ^ 1], 0));
+                    w.comm_pending[w.buf ^ 1] = false;
+                }
+                MCD_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n_out, ncclDouble, ncclSum, slot.comm, slot.stream));
+            }
         }
         if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
-        for (Shard& sh : cat->shards) {
-            WorkSet& w = sh.work.at(W);
-            const DeviceSlot& slot = ctx->slots[sh.slot];
-            MCD_HIP(hipSetDevice(slot.device));
-            MCD_HIP(hipEventRecord(w.ev_comm[w.buf], slot.comm_stream));
-            w.comm_pending[w.buf] = true;
+        if (pipelined) {
+            for (Shard& sh : cat->shards) {
+                WorkSet& w = sh.work.at(W);
+                const DeviceSlot& slot = ctx->slots[sh.slot];
+                MCD_HIP(hipSetDevice(slot.device));
+                MCD_HIP(hipEventRecord(w.ev_comm[w.buf], slot.comm_stream));
+                w.comm_pending[w.buf] = true;
+            }
         }
     }
     if (cat->timing_all) ++cat->timing_launches;
@@ -531,7 +544,7 @@ int fetch(mcd_catalog* cat, double* out) {
         // are NaN-poisoned by the kernel, so the all-reduced results carry the signal to every rank (fetch_once).
         ++cat->n_reruns;
         for (Shard& sh : cat->shards) sh.work.at(W).fast = 0;
-        rc = enqueue(cat);
+        rc = enqueue(cat, false);
         if (rc != MCD_OK) return rc;
         rc = fetch_once(cat, &rerun);
         if (rc != MCD_OK) return rc;
@@ -784,7 +797,7 @@ int mcd_params_upload(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
     return stage_params(cat, n_walkers, k, params, false);
 }
 
-int mcd_loglike_enqueue(mcd_catalog* cat) { return enqueue(cat); }
+int mcd_loglike_enqueue(mcd_catalog* cat) { return enqueue(cat, true); }
 int mcd_loglike_fetch(mcd_catalog* cat, double* out) { return fetch(cat, out); }
 int mcd_sync(mcd_catalog* cat) { return sync_all(cat); }
 
@@ -793,7 +806,7 @@ int mcd_loglike_batch(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
     const bool collective = cat && (cat->ctx->n_ranks > 1 || cat->ctx->slots.size() > 1 || cat->ctx->force_collective);
     int rc = stage_params(cat, n_walkers, k, params, !collective && cat && cat->zero_copy);
     if (rc != MCD_OK) return rc;
-    rc = enqueue(cat);
+    rc = enqueue(cat, false);
     if (rc != MCD_OK) return rc;
     return fetch(cat, out);
 }
