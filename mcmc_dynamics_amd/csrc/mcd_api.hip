@@ -16,6 +16,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -54,7 +55,10 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+std::mutex g_rccl_mutex;
+
 int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);          // contexts may be created from several host threads
     if (g_rccl.handle) return MCD_OK;
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
