@@ -633,3 +633,81 @@ def test_lifetime_order_is_safe(native):
         cat.loglike(pos)
     cat.close()
     ctx2.close()
+
+
+def _realistic_case(rng):
+    """Random catalogue in the ranges of real data (what oracle/crosscheck_reference.py feeds the reference itself)."""
+    n = int(rng.integers(5, 3000))
+    scale_v = 10.0 ** rng.uniform(0, 2.5)
+    sep = np.maximum(np.abs(rng.normal(0, 2.0 / 60.0, n)), 1e-4)
+    th = rng.uniform(-np.pi, np.pi, n)
+    cat = {"ra": CENTRE_RA + sep * np.cos(th) / np.cos(np.radians(CENTRE_DEC)), "dec": CENTRE_DEC + sep * np.sin(th),
+           "v": rng.normal(0, scale_v, n), "verr": 10.0 ** rng.uniform(-2, 1.5) * rng.lognormal(0, 0.7, n)}
+    cat["v"][: min(2, n)] *= 20.0
+    cat["density"] = np.clip(rng.random(n), 0.02, 1.0)
+    cat["pmember"] = np.clip(rng.random(n) * 1.1 - 0.05, 0.0, 1.0)
+    return cat, scale_v
+
+
+CENTRE_RA, CENTRE_DEC = 56.345, -26.675
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 4, 5])
+def test_random_realistic_catalogues_against_the_oracle(native, ctx, model):
+    """Device results (whatever kernel family the guard picks) against the NumPy restatement of the reference on random
+    catalogues and parameter rows in the ranges of real data, fixed and free centre, all six models; 1e-12 relative on
+    the scale max(|lnL|, N)."""
+    from oracle import lnprob_numpy as oracle
+    rng = np.random.default_rng(7000 + model)
+    families = set()
+    for trial in range(24):
+        cat, sv = _realistic_case(rng)
+        n = len(cat["v"])
+        w = int(rng.integers(1, 12))
+        free = bool(trial % 2)
+        cols = [rng.normal(0, sv, w), sv * 10.0 ** rng.uniform(-1.5, 0.7, w)]
+        if model >= 3:
+            cols.append(10.0 ** rng.uniform(0, 2.5, w))                       # a [arcsec]
+        cols += [rng.normal(0, sv, w), rng.normal(0, sv, w)]
+        if model >= 3:
+            cols.append(10.0 ** rng.uniform(0, 2.5, w))                       # r_peak
+        if free:
+            cols += [CENTRE_RA + rng.normal(0, 0.005, w), CENTRE_DEC + rng.normal(0, 0.005, w)]
+        mean_b, sig_b = rng.normal(0, sv), 3 * sv
+        if model in (2, 4):
+            cols += [rng.normal(0, sv, w), sv * 10.0 ** rng.uniform(-0.5, 1.0, w), rng.random(w)]
+        if model == 5:
+            cols.append(rng.random(w))
+        params = np.stack(cols, axis=1)
+        lnbg = oracle.gaussian_background(cat["v"], cat["verr"], mean_b, sig_b)
+        kw = {}
+        if model == 1:
+            kw = dict(lnlike_bg=lnbg, pmember=cat["pmember"])
+        elif model in (2, 4):
+            kw = dict(density=cat["density"])
+        elif model == 5:
+            kw = dict(lnlike_bg=lnbg, density=cat["density"])
+        g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model,
+                           centre=None if free else (CENTRE_RA, CENTRE_DEC), **kw)
+        got = g.loglike(params)
+        families.add(g.fast_level)
+        g.close()
+        want = np.empty(w)
+        for i, row in enumerate(params):
+            rc, dc = (row[6 if model >= 3 else 4], row[7 if model >= 3 else 5]) if free else (CENTRE_RA, CENTRE_DEC)
+            if model == 0:
+                want[i] = oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], rc, dc)
+            elif model == 1:
+                want[i] = oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], rc, dc, lnbg, cat["pmember"])
+            elif model == 2:
+                want[i] = oracle.faithful_constant_gb_lnlike(cat, row[0], row[1], row[2], row[3], rc, dc, *row[-3:])
+            elif model == 3:
+                want[i] = oracle.faithful_model_lnlike(cat, *row[:6], rc, dc)
+            elif model == 4:
+                want[i] = oracle.faithful_model_gb_lnlike(cat, *row[:6], rc, dc, *row[-3:])
+            else:
+                want[i] = oracle.faithful_model_cb_lnlike(cat, *row[:6], rc, dc, row[-1], lnbg)
+        assert np.array_equal(np.isfinite(got), np.isfinite(want)), (trial, got, want)
+        ok = np.isfinite(want)
+        assert np.max(np.abs(got[ok] - want[ok]) / np.maximum(np.abs(want[ok]), n), initial=0.0) < 1e-12, (trial, got, want)
+    assert families <= {0, 1, 2} and (model == 0 or len(families) >= 1)
