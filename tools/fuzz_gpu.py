@@ -28,8 +28,16 @@ def main():
     ap.add_argument("--max-stars", type=int, default=1500)
     ap.add_argument("--max-walkers", type=int, default=200, help="> 256 exercises the XCD-aware workgroup mapping")
     ap.add_argument("--schedule", action="store_true", help="also randomise target_waves / tail_split per case")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="1-rank communicator (MCD_FORCE_RCCL=1): the collective code path, where the re-run signal travels "
+                         "as NaN-poisoned partial sums through the all-reduce")
     a = ap.parse_args()
-    ctx = native.default_context()
+    if a.force_rccl:
+        os.environ["MCD_FORCE_RCCL"] = "1"
+        ctx = native.Context(rank=0, n_ranks=1, unique_id=native.Context.unique_id(), device=0)
+        del os.environ["MCD_FORCE_RCCL"]
+    else:
+        ctx = native.default_context()
     t0 = time.time()
     bad = total = reruns = admitted_inf = 0
     levels = [0, 0, 0]                                     # batches per kernel family (plain / fast / narrow)
