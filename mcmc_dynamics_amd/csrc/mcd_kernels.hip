@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void prepare_records_kernel(RawColumns raw,
         double sa, ca, sd, cd;
         sincos(ra * kDeg2Rad, &sa, &ca);
         sincos(dec * kDeg2Rad, &sd, &cd);
-        r[2] = (T)sa; r[3] = (T)ca; r[4] = (T)sd; r[5] = (T)cd;
+        r[2] = (T)(cd * sa); r[3] = (T)(cd * ca); r[4] = (T)sd; r[5] = (T)0;      // A, B, sin(dec) of free_centre_xy
     } else {
         // calc_xy_offset.py:30-31
         const double dra = (ra - ra_c) * kDeg2Rad;

@@ -90,47 +90,44 @@ MCD_HD float fma_(float a, float b, float c) {
 #endif
 }
 
-// sin(theta), cos(theta) of the position angle about a walker's centre from the star's and the
-// centre's sines/cosines (angle-addition form of calc_xy_offset.py:30-31 followed by
-// arctan2, constant.py:106-107; the r0 factor cancels).  r == 0 follows numpy's arctan2(+0, -0) = pi.
 MCD_HD double rsqrt_nr(double n);
 MCD_HD double rcp_nr(double x);
 
-// Tangent-plane offsets (x, y) of a star about a walker's centre in units of r0 (radians of the orthographic
-// projection), from the sines/cosines of the star's and the centre's coordinates: the angle-addition form of
-// calc_xy_offset.py:30-31.
+// Free centre: tangent-plane offsets of calc_xy_offset.py:30-31 (in units of r0) from per-star products prepared at
+// upload, A = cos(dec) sin(ra), B = cos(dec) cos(ra), sd = sin(dec), and the walker's sin/cos of the centre:
+//   x = -cos(dec) sin(ra - ra_c)                         = B sin(ra_c) - A cos(ra_c)
+//   y = sin(dec) cos(dec_c) - cos(dec) sin(dec_c) cos(ra - ra_c) = sd cos(dec_c) - sin(dec_c) (B cos(ra_c) + A sin(ra_c))
+// Six operations, no per-term trigonometry.
 template <class T>
-MCD_HD void free_centre_xy(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T cdc, T& x, T& y) {
-    T sin_dra = fma_(sa, cac, -(ca * sac));
-    T cos_dra = fma_(ca, cac, sa * sac);
-    x = -(cd * sin_dra);
-    y = fma_(sd, cdc, -(cd * sdc * cos_dra));
+MCD_HD void free_centre_xy(T A, T B, T sd, T sac, T cac, T sdc, T cdc, T& x, T& y) {
+    x = fma_(B, sac, -(A * cac));
+    const T t = fma_(B, cac, A * sac);
+    y = fma_(sd, cdc, -(sdc * t));
 }
 
-// sin(theta), cos(theta) of the position angle theta = arctan2(y, x) (constant.py:106-107; the r0 factor cancels).
-// r == 0 follows numpy's arctan2(+0, -0) = pi.
+// v - v_los for the constant-rotation models with a free centre (constant.py:106-111):
+//   v_los = v_sys + v_maxx sin(theta) - v_maxy cos(theta),  sin(theta) = y / r, cos(theta) = x / r
+//         = v_sys + (v_maxx y - v_maxy x) / r,
+// one reciprocal square root and no separate sin/cos.  r == 0 follows numpy's arctan2(+0, -+0) = pi / 0: sin = 0, cos = -+1.
 template <bool FASTMATH, class T>
-MCD_HD void free_centre_geometry(T sa, T ca, T sd, T cd, T sac, T cac, T sdc, T cdc, T& s, T& c) {
+MCD_HD T free_centre_residual(T A, T B, T sd, T sac, T cac, T sdc, T cdc, T vx, T vy, T v_minus_vsys) {
     T x, y;
-    free_centre_xy(sa, ca, sd, cd, sac, cac, sdc, cdc, x, y);
-    T r2 = fma_(x, x, y * y);
-    if (r2 > T(0)) {
-        T inv;
-        if constexpr (FASTMATH && sizeof(T) == 8) {
-            inv = (T)rsqrt_nr((double)r2);        // offsets are O(1e-9 .. 1) rad: r2 is a normal number
-        } else {
-#if defined(__HIP_DEVICE_COMPILE__)
-            inv = T(1) / sqrt(r2);
-#else
-            inv = T(1) / std::sqrt(r2);
-#endif
-        }
-        s = y * inv;
-        c = x * inv;
+    free_centre_xy(A, B, sd, sac, cac, sdc, cdc, x, y);
+    const T r2 = fma_(x, x, y * y);
+    T inv;
+    if constexpr (FASTMATH && sizeof(T) == 8) {
+        inv = (T)rsqrt_nr((double)r2);            // offsets are O(1e-9 .. 1) rad: r2 is a normal number (or exactly 0)
     } else {
-        s = T(0);
-        c = std::signbit(x) ? T(-1) : T(1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        inv = T(1) / sqrt(r2);
+#else
+        inv = T(1) / std::sqrt(r2);
+#endif
     }
+    const T cross = fma_(vx, y, -(vy * x));
+    const T general = fma_(-cross, inv, v_minus_vsys);
+    const T on_centre = fma_(vy, std::signbit(x) ? T(-1) : T(1), v_minus_vsys);
+    return r2 > T(0) ? general : on_centre;
 }
 
 // a * b + c with the addend c known to be wave-uniform (a star-record value held in an SGPR pair).  hipcc would
@@ -625,16 +622,14 @@ template <class T> MCD_HD T sqrt_(T x) {
 template <int MODEL, class T, bool FREE, bool FASTMATH = false>
 MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T& n) {
     if constexpr (!is_profile(MODEL)) {
-        T s, c;
-        if (FREE) free_centre_geometry<FASTMATH>(r[2], r[3], r[4], r[5], w.sac, w.cac, w.sdc, w.cdc, s, c);
-        else { s = r[2]; c = r[3]; }
-        d = fma_(-w.vx, s, fma_(w.vy, c, r[0] - w.vsys));
+        if (FREE) d = free_centre_residual<FASTMATH>(r[2], r[3], r[4], w.sac, w.cac, w.sdc, w.cdc, w.vx, w.vy, r[0] - w.vsys);
+        else d = fma_(-w.vx, r[2], fma_(w.vy, r[3], r[0] - w.vsys));
         n = r[1] + w.s2;
     } else {
         T dx, dy, r2;
         if (FREE) {
             T x, y;
-            free_centre_xy(r[2], r[3], r[4], r[5], w.sac, w.cac, w.sdc, w.cdc, x, y);
+            free_centre_xy(r[2], r[3], r[4], w.sac, w.cac, w.sdc, w.cdc, x, y);
             dx = T(kArcsecPerRad) * x;
             dy = T(kArcsecPerRad) * y;
             r2 = fma_(dx, dx, dy * dy);

@@ -43,7 +43,8 @@ def pack_records(cat, model, centre):
     n = len(cat["v"])
     cols = [cat["v"], cat["verr"] * cat["verr"]]
     if centre is None:
-        cols += [np.sin(cat["ra"] * DEG), np.cos(cat["ra"] * DEG), np.sin(cat["dec"] * DEG), np.cos(cat["dec"] * DEG)]
+        cd = np.cos(cat["dec"] * DEG)
+        cols += [cd * np.sin(cat["ra"] * DEG), cd * np.cos(cat["ra"] * DEG), np.sin(cat["dec"] * DEG), np.zeros(n)]
     else:
         dra = (cat["ra"] - centre[0]) * DEG
         dr, dc = cat["dec"] * DEG, centre[1] * DEG
