@@ -356,6 +356,7 @@ def main():
     kernel_ms_total, n_launch = gpu_cat.timing_collect()
     result = gpu_cat.fetch()
     info = gpu_cat.launch_info()
+    info["kernel_family"] = {0: "plain", 1: "fast", 2: "fast, narrow-range variant", -1: "none"}[gpu_cat.fast_level]
 
     # blocking C-ABI call (host params in, host results out) for the PCIe/sync-inclusive rate
     gpu_cat.set_option("timing", 0)
