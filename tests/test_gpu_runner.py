@@ -218,3 +218,15 @@ def test_model_fit_profiles_and_full_size():
     chain = np.broadcast_to(pos[:, None, :], (128, 12, 6)) * (1.0 + 0.01 * rng.normal(size=(128, 12, 6)))
     prof = mf.create_profiles(chain, n_burn=2, radii=[10.0, 60.0, 200.0])
     assert len(prof) == 3 and prof["v_rot"][1] == pytest.approx(5.0, rel=0.2) and prof["sigma"][0] < 10.6
+
+
+def test_example_script_runs(tmp_path):
+    """examples/run_constant_fit.py end to end (synthetic cluster -> ConstantFit + background -> MCMC -> tables)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "run_constant_fit.py"), "--stars", "5000",
+                          "--walkers", "32", "--steps", "40"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "acceptance fraction" in res.stdout and "sigma_max" in res.stdout and "theta_0" in res.stdout
