@@ -40,6 +40,7 @@ def main():
         ctx = native.default_context()
     t0 = time.time()
     bad = total = reruns = admitted_inf = 0
+    worst_case = None
     levels = [0, 0, 0]                                     # batches per kernel family (plain / fast / narrow)
     worst = 0.0
     for trial in range(a.trials):
@@ -80,7 +81,8 @@ def main():
                     g.set_option("target_waves", int(rng.integers(1, 20000)))
                     g.set_option("tail_split", int(rng.integers(0, 3)))
                 fast = g.loglike(params)
-                levels[g.fast_level] += 1
+                g_level = g.fast_level
+                levels[g_level] += 1
                 reruns += g.rerun_count
                 g.set_option("fast_path", 0)
                 plain = g.loglike(params)
@@ -92,7 +94,8 @@ def main():
                 # every term is O(1 .. 10): a total that cancels to less than n is judged on the scale n
                 err = float(np.max(np.abs(fast[ok] - plain[ok]) / np.maximum(np.abs(plain[ok]), float(n)))) if ok.any() else 0.0
                 admitted_inf += int(np.isneginf(plain).sum())
-                worst = max(worst, err)
+                if err > worst:
+                    worst, worst_case = err, (seed, model, free, n, w, g_level)
                 if not same or err > 1e-11:
                     bad += 1
                     print("MISMATCH seed", seed, "model", model, "free", free, "n", n, "w", w, "pattern_same", same, "err", err,
@@ -101,6 +104,7 @@ def main():
             print("trial", trial, "cases", total, "bad", bad, "worst rel err", worst, "reruns", reruns, "-inf walkers", admitted_inf,
                   "elapsed %.0f s" % (time.time() - t0), flush=True)
     print("kernel families chosen (plain, fast, narrow):", levels)
+    print("worst case (seed, model, free centre, stars, walkers, family):", worst_case)
     print("DONE cases", total, "bad", bad, "worst rel err", worst, "reruns", reruns, "-inf walkers", admitted_inf, flush=True)
     return 1 if bad else 0
 
