@@ -272,3 +272,45 @@ def test_narrow_range_constant_background_profile_variant(which):
     zero_f = values.copy()
     zero_f[0, -1] = 0.0
     assert emul.fast_level(cat, zero_f, 5, centre) == 1
+
+
+@pytest.mark.parametrize("name,model", [("constant_fixed", 0), ("constant_bg_gaussian_fixed", 1), ("constant_gb_fixed", 2)])
+def test_fast_formulations_are_as_accurate_as_the_float64_reference(name, model):
+    """Accuracy, not only agreement: against an 80-bit (numpy.longdouble) evaluation of the reference's formulas the fast
+    formulations (fraction tree / log-product / table exp / Newton rsqrt) must not be further from the exact value than
+    the reference's own float64 arithmetic is."""
+    from oracle import lnprob_numpy as oracle
+    L = np.longdouble
+    if np.finfo(L).eps > 1e-18:
+        pytest.skip("no extended-precision long double on this platform")
+    g = load_golden(name)
+    keys = ("ra", "dec", "v", "verr") + (("pmember",) if model == 1 else ()) + (("density",) if model == 2 else ())
+    cat = {k: g[k] for k in keys}
+    if model == 1:
+        cat["lnlike_bg"] = g["lnlike_background"]
+    centre = (float(g["ra_center"]), float(g["dec_center"]))
+    names = [str(x) for x in g["names"]]
+    ok = np.isfinite(g["lnprob"]) & (g["values"][:, names.index("sigma_max")] > 0)
+    if model == 2:
+        ok &= g["values"][:, names.index("f_back")] > 1e-6
+    rows = g["values"][ok]
+    catL = {k: v.astype(L) for k, v in cat.items()}
+    exact = np.empty(len(rows), dtype=L)
+    for i, row in enumerate(rows.astype(L)):
+        if model == 0:
+            exact[i] = oracle.faithful_constant_lnlike(catL, row[0], row[1], row[2], row[3], L(centre[0]), L(centre[1]))
+        elif model == 1:
+            lnbgL = oracle.gaussian_background(catL["v"], catL["verr"], L(float(g["bg_mean"])), L(float(g["bg_sigma"])))
+            exact[i] = oracle.faithful_constant_lnlike(catL, row[0], row[1], row[2], row[3], L(centre[0]), L(centre[1]), lnbgL, catL["pmember"])
+        else:
+            exact[i] = oracle.faithful_constant_gb_lnlike(catL, row[0], row[1], row[2], row[3], L(centre[0]), L(centre[1]), row[4], row[5], row[6])
+    reference64 = g["lnprob"][ok]                                    # the reference itself, float64
+    level = emul.fast_level(cat, emul.abi_columns(g["names"], rows, model, False), model, centre)
+    assert level >= 1
+    fast = emul.loglike(cat, emul.abi_columns(g["names"], rows, model, False), model, centre, level, 248)
+    err_ref = np.max(np.abs((reference64.astype(L) - exact) / exact)).astype(float)
+    err_fast = np.max(np.abs((fast.astype(L) - exact) / exact)).astype(float)
+    # (the common floor, up to 1e-12, is the float64 trigonometry of calc_xy_offset for stars next to the centre, which the
+    #  device kernels inherit through the same float64 inputs)
+    assert err_fast < 5e-12 and err_ref < 5e-12
+    assert err_fast <= 2.0 * err_ref + 4e-16, (err_fast, err_ref)
