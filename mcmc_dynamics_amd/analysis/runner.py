@@ -54,6 +54,21 @@ class _BatchPlan(object):
         fac = [units.conversion_factor(pars[n].unit, u) if (pars[n].unit and u) else 1.0 for n, u in cols]
         self.kernel_fac = None if all(f == 1.0 for f in fac) else np.array(fac, dtype=np.float64)
         self.catalog_key = key
+        # Direct route for the common case (every kernel column is a FREE parameter, flat bounds): the (W, P) proposal array
+        # is checked and handed to the kernel without building the (W, n_all) table first.  The fixed parameters are
+        # constants: their bounds are verified here once (the reference re-checks them per call, runner.py:207-214).
+        free_pos = {int(i): pos for pos, i in enumerate(self.free_idx)}
+        self.direct_cols = None
+        if self.simple and all(int(i) in free_pos for i in self.kernel_idx):
+            cols_ = np.array([free_pos[int(i)] for i in self.kernel_idx], dtype=np.intp)
+            self.direct_cols = cols_
+            self.direct_identity = bool(cols_.size == self.free_idx.size and np.array_equal(cols_, np.arange(cols_.size)))
+            self.fixed_ok = bool(np.all((self.fixed_val >= self.lo[self.fixed_idx]) & (self.fixed_val <= self.hi[self.fixed_idx]))) \
+                if self.fixed_idx.size else True
+            free_lo, free_hi = self.lo[self.free_idx], self.hi[self.free_idx]
+            self.lo_cols = np.flatnonzero(~np.isneginf(free_lo))
+            self.hi_cols = np.flatnonzero(~np.isposinf(free_hi))
+            self.lo_vals, self.hi_vals = free_lo[self.lo_cols], free_hi[self.hi_cols]
 
     @staticmethod
     def signature(runner):
@@ -75,6 +90,21 @@ class _BatchPlan(object):
 
     def table(self, full):
         t = full[:, self.kernel_idx]
+        return t if self.kernel_fac is None else t * self.kernel_fac
+
+    def prior_ok_free(self, values):
+        """`prior_ok` from the (W, P) proposals alone (direct route)."""
+        if not self.fixed_ok:
+            return np.zeros(values.shape[0], dtype=bool)
+        ok = ~np.isnan(values).any(axis=1)
+        if self.lo_cols.size:
+            ok &= (values[:, self.lo_cols] >= self.lo_vals).all(axis=1)
+        if self.hi_cols.size:
+            ok &= (values[:, self.hi_cols] <= self.hi_vals).all(axis=1)
+        return ok
+
+    def table_direct(self, values):
+        t = values if self.direct_identity else values[:, self.direct_cols]
         return t if self.kernel_fac is None else t * self.kernel_fac
 
 
@@ -243,6 +273,23 @@ class Runner(object):
         a valid row for the launch and masked afterwards (the reference skips the evaluation)."""
         values = np.atleast_2d(np.asarray(values, dtype=np.float64))
         plan = self._plan()
+        if plan.direct_cols is not None and values.shape[1] == plan.free_idx.size:
+            ok = plan.prior_ok_free(values)
+            n_ok = int(np.count_nonzero(ok))
+            if n_ok == 0:
+                return np.full(values.shape[0], -np.inf)
+            if n_ok != ok.size:
+                values = values.copy()
+                values[~ok] = values[int(np.flatnonzero(ok)[0])]
+            cat = self._catalog
+            if cat is None or plan.catalog_key != self._catalog_key:
+                cat = self._ensure_catalog()
+            ll = cat.loglike(plan.table_direct(values))
+            if n_ok == ok.size:
+                return ll
+            out = np.full(values.shape[0], -np.inf)
+            out[ok] = ll[ok]
+            return out
         if plan.simple and values.shape[1] == plan.free_idx.size:
             # fast host path: flat bounds, no expression priors / constraints
             full = plan.full(values)
