@@ -297,3 +297,53 @@ def test_batch_plan_matches_the_per_parameter_path():
         obj.parameters["v_sys"].set(max=0.0)
         again = obj.lnprob_batch(vals)
         assert np.array_equal(np.isfinite(again), ok & (vals[:, 0] <= 0.0))
+
+
+def test_lnprob_batch_direct_route_equals_the_general_one(monkeypatch):
+    """`Runner.lnprob_batch` hands the (W, P) proposals straight to the kernel when every kernel column is a free
+    parameter; verdicts (prior violations, NaN) and the table the kernel receives must equal those of the general route
+    through the full (W, n_all) parameter table.  No GPU: the catalogue is a stub that records what it is given."""
+    import mcmc_dynamics_amd.analysis.runner as runner_mod
+    from mcmc_dynamics_amd.analysis import ConstantFitGB
+
+    class StubCatalog(object):
+        seen = None
+
+        def loglike(self, p):
+            self.seen = np.array(p)
+            return np.arange(len(p), dtype=np.float64)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(runner_mod.Runner, "_ensure_catalog", lambda self: self._catalog)
+    cat = synthetic.make_catalog(500, config=3, background=True)
+    names7 = ["v_sys", "sigma_max", "v_maxx", "v_maxy", "v_back", "sigma_back", "f_back"]
+    for cls, names, cols, kw in ((ConstantFit, names7[:4], ("ra", "dec", "v", "verr", "pmember"), dict(background=Gaussian(20.0, 40.0))),
+                                 (ConstantFitGB, names7, ("ra", "dec", "v", "verr", "density"), {})):
+        fit = cls(DataReader({k: cat[k] for k in cols}), **kw)
+        fit.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)
+        fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
+        fit._catalog = StubCatalog()
+        plan = fit._plan()
+        fit._catalog_key = plan.catalog_key
+        assert plan.direct_cols is not None and plan.direct_identity
+        pos = synthetic.make_walkers(64, names, cat["truth"], config=3)
+        rng = np.random.default_rng(3)
+        for trial in range(50):
+            x = pos * (1.0 + 0.5 * rng.normal(size=pos.shape))
+            x[rng.integers(0, 64, 4), 1] *= -1.0                  # sigma_max < 0
+            if trial % 5 == 0:
+                x[3, 0] = np.nan
+            got = fit.lnprob_batch(x)
+            full = plan.full(x)
+            ok = plan.prior_ok(full)
+            assert np.array_equal(np.isfinite(got), ok)
+            if ok.any():
+                if not ok.all():
+                    full[~ok] = full[int(np.flatnonzero(ok)[0])]
+                assert np.array_equal(fit._catalog.seen, plan.table(full))
+        fit.parameters["v_sys"].set(value=0.0, fixed=True)       # a fixed kernel column: back to the general route
+        assert fit._plan().direct_cols is None
+        fit._catalog_key = fit._plan().catalog_key
+        assert fit.lnprob_batch(pos[:, 1:]).shape == (64,)
