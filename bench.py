@@ -232,8 +232,8 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 0:
-            # Degraded mode (recorded in the JSON line): every rank still evaluates its own star shard, but the
-            # per-walker partial sums are NOT exchanged inside the timed loop.
+            # Degraded mode (recorded in the JSON line): every rank still evaluates its own star shard and the per-walker
+            # partial sums are exchanged over the host process group instead (see the timed loop).
             if ok:
                 ctx.close()
             ctx = native.Context(n_devices=1, device_ids=[local_rank])
@@ -343,9 +343,19 @@ def main():
     barrier()
     gpu_cat.timing_collect()                         # drop ramp and warm-up launches
 
+    # Degraded mode (RCCL unavailable): the exchange is NOT skipped -- every step fetches the rank's partial sums and
+    # all-reduces them over the host process group (gloo), which serialises the steps; the JSON line says so.
+    host_exchange = dist is not None and rccl_note.startswith("unavailable")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gpu_cat.enqueue()
+    if host_exchange:
+        import torch
+        for _ in range(args.steps):
+            gpu_cat.enqueue()
+            part = torch.from_numpy(gpu_cat.fetch())
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+    else:
+        for _ in range(args.steps):
+            gpu_cat.enqueue()
     gpu_cat.sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -424,7 +434,7 @@ def main():
         "config": {"workload": desc, "stars_per_gpu": len(cat["v"]), "stars_total": total_stars, "walkers": n_walkers,
                    "likelihood": model, "parallelism": ("stars sharded over {0} rank(s); ".format(world) +
                                    ("RCCL all-reduce of {0} doubles per step".format(n_walkers)
-                                    if rccl_note and not rccl_note.startswith("unavailable") else "NO collective (RCCL unavailable)"))
+                                    if rccl_note and not rccl_note.startswith("unavailable") else "RCCL unavailable: per-step exchange over the host process group (gloo all-reduce of the fetched partial sums)"))
                    if world > 1 else "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
