@@ -1,6 +1,6 @@
 """Measure mcd_kde_background (background.SingleStars on the device) and check a sample against the oracle.
 
-    python tools/kde_probe.py [--stars 1000000] [--comp 10000] [--repeat 5]
+    python tests/probes/kde_probe.py [--stars 1000000] [--comp 10000] [--repeat 5]
 
 Prints one JSON line: pairs/s from the HIP-event time of the two kernels, the blocking-call wall time (host buffers in
 and out, PCIe included) and the NumPy restatement's rate on a bounded sample of the same test stars."""
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mcmc_dynamics_amd import _native  # noqa: E402
 from oracle import lnprob_numpy as oracle  # noqa: E402  (checker + CPU baseline only)
 

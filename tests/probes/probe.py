@@ -1,7 +1,7 @@
 """Scratch perf probe (not part of the product): times the main kernel at BASELINE shapes."""
 import sys, time
 import numpy as np
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from mcmc_dynamics_amd import _native, synthetic
 from oracle import lnprob_numpy as oracle
 

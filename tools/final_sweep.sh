@@ -19,7 +19,7 @@ done
 for p in f64 f32acc64 f32; do
     timeout -k 10 300 python bench.py --workload c5 --precision $p > $O/bench_c5_$p.json 2> $O/bench_c5_$p.err || exit 1
 done
-timeout -k 10 200 python tools/kde_probe.py > $O/kde_probe_$TAG.json 2> $O/kde_probe.err || exit 1
+timeout -k 10 200 python tests/probes/kde_probe.py > $O/kde_probe_$TAG.json 2> $O/kde_probe.err || exit 1
 echo "benches done"
 rm -rf $O/prof_${TAG}_c3 $O/prof_${TAG}_c2 $O/pmc_fetch_$TAG $O/pmc_write_$TAG
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c3 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c3.log 2>&1 || exit 1
