@@ -101,6 +101,8 @@ typedef struct {
 /* Single process driving n_dev devices (dev_ids == NULL: devices 0..n_dev-1).  With n_dev > 1 the
  * catalogue is sharded over the devices and per-walker partial sums are combined with one
  * ncclAllReduce(sum, f64, count = outputs) per batched call (communicator from ncclCommInitAll). */
+/* MCD_FORCE_RCCL=1 in the environment: a one-device context also creates its communicator with ncclCommInitAll and
+ * runs the all-reduce inside ncclGroupStart/End (lets a single-GPU box exercise the call sequence of this mode). */
 int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out);
 
 /* One process per GPU (torchrun-style).  Rank 0 calls mcd_get_unique_id and distributes the
@@ -114,6 +116,10 @@ int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id
 
 int mcd_ctx_destroy(mcd_ctx* ctx);
 int mcd_ctx_n_devices(const mcd_ctx* ctx);
+/* What RCCL itself reports for the communicator of the context's first device: ncclCommCount, ncclCommUserRank and
+ * ncclGetVersion (e.g. 22707).  comm_size = 0 / comm_rank = -1 when the context has no communicator (single device:
+ * RCCL is never loaded).  A measurement harness echoes these to prove the collective really spans N ranks. */
+int mcd_ctx_comm_info(const mcd_ctx* ctx, int* comm_size, int* comm_rank, int* rccl_version);
 
 /* ---- catalogue ---------------------------------------------------------------------------- */
 

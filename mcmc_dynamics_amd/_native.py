@@ -11,7 +11,8 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcd_hip.so")
+# MCD_LIB_PATH: A/B builds of the same library for kernel experiments (csrc/Makefile: variant); default = the in-tree build
+LIB_PATH = os.environ.get("MCD_LIB_PATH") or os.path.join(_HERE, "libmcd_hip.so")
 
 MODEL_CONST, MODEL_CONST_BGFIXED, MODEL_CONST_BGGAUSS = 0, 1, 2
 MODEL_PROFILE, MODEL_PROFILE_BGGAUSS, MODEL_PROFILE_BGDENS = 3, 4, 5
@@ -31,6 +32,8 @@ SYMBOLS = {
                                            ctypes.POINTER(ctypes.c_void_p)]),
     "mcd_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_ctx_n_devices": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_ctx_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                         ctypes.POINTER(ctypes.c_int)]),
     "mcd_catalog_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "mcd_catalog_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_catalog_param_count": (ctypes.c_int, [ctypes.c_void_p]),
@@ -169,6 +172,13 @@ class Context(object):
     @property
     def n_devices(self):
         return self.lib.mcd_ctx_n_devices(self.handle)
+
+    def comm_info(self):
+        """What RCCL reports for this context's communicator: {'size', 'rank', 'rccl_version'} (size 0: none)."""
+        n, r, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(self.lib, self.lib.mcd_ctx_comm_info(self.handle, ctypes.byref(n), ctypes.byref(r), ctypes.byref(v)),
+               "mcd_ctx_comm_info")
+        return {"size": n.value, "rank": r.value, "rccl_version": v.value}
 
     def kde_background(self, comp, v, verr, sigma_int=0.0, return_kernel_ms=False):
         """``background.SingleStars.__call__`` (single_stars.py:42-77) for km/s arrays: (n,) log-likelihoods."""

@@ -52,6 +52,9 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 Rccl g_rccl;
 
@@ -75,6 +78,9 @@ int load_rccl() {
     MCD_SYM(GroupStart, "ncclGroupStart")
     MCD_SYM(GroupEnd, "ncclGroupEnd")
     MCD_SYM(GetErrorString, "ncclGetErrorString")
+    MCD_SYM(CommCount, "ncclCommCount")
+    MCD_SYM(CommUserRank, "ncclCommUserRank")
+    MCD_SYM(GetVersion, "ncclGetVersion")
 #undef MCD_SYM
     g_rccl.handle = h;
     return MCD_OK;
@@ -105,7 +111,7 @@ struct WorkSet {
     uint8_t* d_chunk_general = nullptr;   // [n_chunks] chunks excluded from the narrow-range variant; null when there are none
     double* d_params = nullptr;        // [n_psets][W][K]
     void* d_wpar = nullptr;            // [n_psets][W][KD]
-    double* d_partials = nullptr;      // [W][n_chunks]
+    double* d_partials = nullptr;      // [roundup64(W) / 8][n_chunks][8]
     double* d_out = nullptr;           // [n_psets][W] (+ flag word)
     double* d_out2 = nullptr;          // second result buffer: collective mode alternates between the two, so that the
                                        // all-reduce of step i (comm stream) overlaps the kernels of step i + 1
@@ -185,8 +191,6 @@ int param_count(int model, bool free_centre) {
     return k;
 }
 
-int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-
 void free_workset(WorkSet& w) {
     if (w.d_chunks) (void)hipFree(w.d_chunks);
     if (w.d_offsets) (void)hipFree(w.d_offsets);
@@ -205,78 +209,31 @@ void free_workset(WorkSet& w) {
     w = WorkSet();
 }
 
-// Chunk table of one shard for a given walker count: every parameter set (bin) is cut into runs of
-// `len` stars (a multiple of 8 so that only the last chunk of a set has a tail).
+// Work buffers of one shard for a given walker count; the chunk table itself is planned by mcd_chunks.h: plan_chunks
+// (host-only, unit-tested on the CPU).
 int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out) {
     auto it = sh.work.find(n_walkers);
     if (it != sh.work.end()) { *out = &it->second; return MCD_OK; }
     if (sh.work.size() >= 8) {                       // bound the cache (emcee uses W and W/2)
         for (auto& kv : sh.work) free_workset(kv.second);
         sh.work.clear();
+        cat->cur_walkers = 0;                        // whatever was staged is gone; stage_params sets it again on success
     }
     const DeviceSlot& slot = cat->ctx->slots[sh.slot];
     MCD_HIP(hipSetDevice(slot.device));
 
-    const int64_t n_wtiles = (n_walkers + 63) / 64;
-    int64_t len = (sh.n * n_wtiles + cat->target_waves - 1) / std::max<int64_t>(1, cat->target_waves);
-    len = std::max<int64_t>(64, round_up(len, 32));          // quarter-length tail chunks stay multiples of 8
-
-    std::vector<mcd::Chunk> chunks;
-    std::vector<int64_t> offs(cat->n_psets + 1, 0);
-    int64_t max_per = 0;
-    for (int64_t p = 0; p < cat->n_psets; ++p) {
-        offs[p] = (int64_t)chunks.size();
-        const int64_t b0 = std::max(cat->bin_offsets[p], sh.star_begin);
-        const int64_t b1 = std::min(cat->bin_offsets[p + 1], sh.star_begin + sh.n);
-        // Guided schedule: workgroups are dispatched in chunk order, so the end of a large parameter set is cut
-        // into shorter chunks -- the waves that finish the launch are short, which trims the idle tail of the
-        // last occupancy round.  (tail_split: 0 equal chunks; 1 = 85/10/5 % at len, len/2, len/4; 2 = 70/15/10/5 %
-        // down to len/8; 3, 4 = guided self-scheduling, chunk = remaining work / (G x resident waves).)
-        const int64_t total = b1 - b0;
-        const int mode = (total >= 16 * len && len >= 128) ? cat->tail_split : 0;
-        const int64_t resident_chunks = std::max<int64_t>(1, 8192 / n_wtiles);
-        for (int64_t s = b0; s < b1;) {
-            const int64_t done = s - b0, rem = b1 - s;
-            int64_t step = len;
-            if (mode == 1) step = done * 100 < total * 85 ? len : (done * 100 < total * 95 ? len / 2 : len / 4);
-            else if (mode == 2) step = done * 100 < total * 70 ? len : (done * 100 < total * 85 ? len / 2 : (done * 100 < total * 95 ? len / 4 : len / 8));
-            else if (mode == 3) step = std::min(len, std::max<int64_t>(64, rem / (2 * resident_chunks) / 8 * 8));
-            else if (mode == 4) step = std::min(len, std::max<int64_t>(128, rem / resident_chunks / 8 * 8));
-            step = std::max<int64_t>(8, step / 8 * 8);
-            mcd::Chunk c;
-            c.begin = s - sh.star_begin;
-            c.count = (int32_t)std::min(step, rem);
-            c.pset = (int32_t)p;
-            chunks.push_back(c);
-            s += step;
-        }
-        max_per = std::max<int64_t>(max_per, (int64_t)chunks.size() - offs[p]);
-    }
-    offs[cat->n_psets] = (int64_t)chunks.size();
+    const mcd::ChunkPlan plan = mcd::plan_chunks(cat->bin_offsets, sh.star_begin, sh.n, n_walkers, cat->target_waves,
+                                                 cat->tail_split, cat->stats.narrow_exceptions);
+    const std::vector<mcd::Chunk>& chunks = plan.chunks;
+    const std::vector<int64_t>& offs = plan.offsets;
+    const std::vector<uint8_t>& general = plan.general;
 
     WorkSet w;
     w.n_walkers = n_walkers;
     w.n_chunks = (int64_t)chunks.size();
-    w.max_chunks_per_pset = max_per;
-    if (cat->n_psets == 1 && !chunks.empty() && len < (int64_t)1 << 30) {
-        bool uniform = true;
-        for (size_t i = 0; i < chunks.size() && uniform; ++i)
-            uniform = chunks[i].begin == (int64_t)i * len && chunks[i].count == (int32_t)std::min<int64_t>(len, sh.n - (int64_t)i * len);
-        if (uniform) w.uniform_len = (int)len;
-    }
-    // chunks holding a star that rules out the narrow-range variants (stats.narrow_exceptions: ascending global indices)
-    std::vector<uint8_t> general;
-    const std::vector<int64_t>& exc = cat->stats.narrow_exceptions;
-    if (!exc.empty()) {
-        general.assign(chunks.size(), 0);
-        bool any = false;
-        for (size_t i = 0; i < chunks.size(); ++i) {
-            const int64_t lo = sh.star_begin + chunks[i].begin, hi = lo + chunks[i].count;
-            const auto it2 = std::lower_bound(exc.begin(), exc.end(), lo);
-            if (it2 != exc.end() && *it2 < hi) { general[i] = 1; any = true; }
-        }
-        if (!any) general.clear();
-    }
+    w.max_chunks_per_pset = plan.max_chunks_per_pset;
+    w.uniform_len = plan.uniform_len;
+    const int64_t padded_walkers = (n_walkers + 63) / 64 * 64;       // partial sums: whole walker tiles (mcd_kernels.hip)
     const int64_t n_out = cat->n_psets * n_walkers;
     const size_t term_bytes = cat->precision == MCD_F64 ? 8 : 4;
     auto allocate = [&]() -> hipError_t {
@@ -289,7 +246,7 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
         if ((e = hipMalloc(&w.d_offsets, offs.size() * sizeof(int64_t))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_params, (size_t)n_out * cat->k * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_wpar, (size_t)n_out * mcd::KD * term_bytes)) != hipSuccess) return e;
-        if ((e = hipMalloc(&w.d_partials, std::max<size_t>(1, (size_t)n_walkers * w.n_chunks) * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&w.d_partials, std::max<size_t>(1, (size_t)padded_walkers * w.n_chunks) * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_out, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;   // + re-run flag word
         if ((e = hipMemset(w.d_out, 0, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_out2, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
@@ -318,13 +275,28 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     return MCD_OK;
 }
 
+// Work buffers staged for walker count W (nullptr when the cache no longer holds them, e.g. after a failed upload)
+WorkSet* find_work(Shard& sh, int64_t W) {
+    const auto it = sh.work.find(W);
+    return it == sh.work.end() ? nullptr : &it->second;
+}
+
+bool all_staged(mcd_catalog* cat) {
+    if (cat->cur_walkers <= 0) return false;
+    for (Shard& sh : cat->shards) {
+        const WorkSet* w = find_work(sh, cat->cur_walkers);
+        if (!w || !w->staged) return false;
+    }
+    return true;
+}
+
 int fast_level(const mcd_catalog* cat, const double* params, int64_t n_rows) {
     if (!cat->allow_fast) return 0;
     const int level = mcd::fast_level(cat->stats, cat->model, cat->free_centre, cat->precision != MCD_F64, cat->k, params, n_rows);
     return cat->allow_fast == 2 && level > 1 ? 1 : level;
 }
 
-int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, bool zero_copy) {
+int stage_params_impl(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, bool zero_copy) {
     if (!cat || !params) return fail(MCD_ERR_INVALID, "null catalogue or params");
     if (n_walkers <= 0) return fail(MCD_ERR_INVALID, "n_walkers must be positive");
     if (k != cat->k) {
@@ -362,18 +334,26 @@ int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* p
     return MCD_OK;
 }
 
+// A failed upload leaves nothing staged: a later enqueue / fetch answers MCD_ERR_INVALID instead of working on buffers
+// that may have been evicted.
+int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, bool zero_copy) {
+    const int rc = stage_params_impl(cat, n_walkers, k, params, zero_copy);
+    if (rc != MCD_OK && cat) cat->cur_walkers = 0;
+    return rc;
+}
+
 // pipelined (mcd_loglike_enqueue): the all-reduce goes to the communication stream and overlaps the next step's kernels.
 // A blocking call gains nothing from that hop: its all-reduce stays on the compute stream (after any collective still
 // pending on the communication stream, so that operations on one communicator never run concurrently).
 int enqueue(mcd_catalog* cat, bool pipelined) {
     if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
     if (cat->cur_walkers <= 0) return fail(MCD_ERR_INVALID, "no parameters staged (call mcd_params_upload first)");
+    if (!all_staged(cat)) return fail(MCD_ERR_INVALID, "no parameters staged for this walker count (the last upload failed?)");
     const int64_t W = cat->cur_walkers;
     const int64_t n_out = cat->n_psets * W;
     mcd_ctx* ctx = cat->ctx;
     for (Shard& sh : cat->shards) {
-        WorkSet& w = sh.work.at(W);
-        if (!w.staged) return fail(MCD_ERR_INVALID, "no parameters staged for this walker count");
+        WorkSet& w = (*find_work(sh, W));
         const DeviceSlot& slot = ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast, w.uniform_len, sh.n};
@@ -430,7 +410,7 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
     if (collective) {
         if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
         for (Shard& sh : cat->shards) {
-            WorkSet& w = sh.work.at(W);
+            WorkSet& w = (*find_work(sh, W));
             const DeviceSlot& slot = ctx->slots[sh.slot];
             MCD_HIP(hipSetDevice(slot.device));
             double* buf = w.buf ? w.d_out2 : w.d_out;
@@ -448,7 +428,7 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
         if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
         if (pipelined) {
             for (Shard& sh : cat->shards) {
-                WorkSet& w = sh.work.at(W);
+                WorkSet& w = (*find_work(sh, W));
                 const DeviceSlot& slot = ctx->slots[sh.slot];
                 MCD_HIP(hipSetDevice(slot.device));
                 MCD_HIP(hipEventRecord(w.ev_comm[w.buf], slot.comm_stream));
@@ -468,10 +448,9 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
         cat->timing_pending = true;
     }
     {
-        WorkSet& w0 = cat->shards[0].work.at(W);
-        const int64_t n_wtiles = (W + 63) / 64;
+        WorkSet& w0 = (*find_work(cat->shards[0], W));
         cat->last_chunks = w0.n_chunks;
-        cat->last_grid = n_wtiles <= 4 ? (w0.n_chunks * n_wtiles + 3) / 4 : (w0.n_chunks + 7) / 8 * 8 * ((n_wtiles + 3) / 4);
+        cat->last_grid = mcd::main_grid(w0.n_chunks, W);
     }
     return MCD_OK;
 }
@@ -508,7 +487,7 @@ int fetch_once(mcd_catalog* cat, bool* rerun) {
     const bool coll = cat->ctx->n_ranks > 1 || cat->ctx->slots.size() > 1 || cat->ctx->force_collective;
     bool any_fast = false;
     for (Shard& sh : cat->shards) {
-        WorkSet& w = sh.work.at(W);
+        WorkSet& w = (*find_work(sh, W));
         any_fast = any_fast || w.fast != 0;
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
@@ -521,7 +500,7 @@ int fetch_once(mcd_catalog* cat, bool* rerun) {
     }
     int rc = sync_all(cat);
     if (rc != MCD_OK) return rc;
-    const WorkSet& w0 = cat->shards[0].work.at(W);
+    const WorkSet& w0 = (*find_work(cat->shards[0], W));
     if (coll) {
         // Every rank decides on the all-reduced values alone (identical everywhere), whatever kernel family it ran itself:
         // the re-evaluation is collective.  (A NaN that the plain kernels produce legitimately costs one extra pass.)
@@ -534,7 +513,7 @@ int fetch_once(mcd_catalog* cat, bool* rerun) {
 
 int fetch(mcd_catalog* cat, double* out) {
     if (!cat || !out) return fail(MCD_ERR_INVALID, "null catalogue or output");
-    if (cat->cur_walkers <= 0) return fail(MCD_ERR_INVALID, "nothing evaluated yet");
+    if (cat->cur_walkers <= 0 || !all_staged(cat)) return fail(MCD_ERR_INVALID, "nothing evaluated yet");
     const int64_t W = cat->cur_walkers;
     const int64_t n_out = cat->n_psets * W;
     bool rerun = false;
@@ -547,13 +526,13 @@ int fetch(mcd_catalog* cat, double* out) {
         // multi-rank job every rank takes the same decision (the all-reduce is collective): the affected partial sums
         // are NaN-poisoned by the kernel, so the all-reduced results carry the signal to every rank (fetch_once).
         ++cat->n_reruns;
-        for (Shard& sh : cat->shards) sh.work.at(W).fast = 0;
+        for (Shard& sh : cat->shards) (*find_work(sh, W)).fast = 0;
         rc = enqueue(cat, false);
         if (rc != MCD_OK) return rc;
         rc = fetch_once(cat, &rerun);
         if (rc != MCD_OK) return rc;
     }
-    std::memcpy(out, cat->shards[0].work.at(W).h_out, (size_t)n_out * sizeof(double));
+    std::memcpy(out, (*find_work(cat->shards[0], W)).h_out, (size_t)n_out * sizeof(double));
     return MCD_OK;
 }
 
@@ -591,7 +570,11 @@ int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out) {
         int rc = make_slot(ids[i], &ctx->slots[i]);
         if (rc != MCD_OK) return rc;
     }
-    if (n_dev > 1) {
+    // MCD_FORCE_RCCL=1: also a one-device context gets its communicator from ncclCommInitAll and all-reduces inside
+    // ncclGroupStart/End, so that a single-GPU box runs the call sequence of the multi-device mode
+    const char* force = std::getenv("MCD_FORCE_RCCL");
+    ctx->force_collective = n_dev == 1 && force && force[0] == '1';
+    if (n_dev > 1 || ctx->force_collective) {
         int rc = load_rccl();
         if (rc != MCD_OK) return rc;
         std::vector<ncclComm_t> comms(n_dev);
@@ -657,6 +640,23 @@ int mcd_ctx_destroy(mcd_ctx* ctx) {
 }
 
 int mcd_ctx_n_devices(const mcd_ctx* ctx) { return ctx ? (int)ctx->slots.size() : 0; }
+
+int mcd_ctx_comm_info(const mcd_ctx* ctx, int* comm_size, int* comm_rank, int* rccl_version) {
+    if (!ctx || ctx->slots.empty()) return fail(MCD_ERR_INVALID, "mcd_ctx_comm_info: null context");
+    if (comm_size) *comm_size = 0;
+    if (comm_rank) *comm_rank = -1;
+    if (rccl_version) *rccl_version = 0;
+    const ncclComm_t comm = ctx->slots[0].comm;
+    if (!comm) return MCD_OK;                       // single device, RCCL never loaded
+    int n = 0, r = -1, v = 0;
+    MCD_NCCL(g_rccl.CommCount(comm, &n));
+    MCD_NCCL(g_rccl.CommUserRank(comm, &r));
+    MCD_NCCL(g_rccl.GetVersion(&v));
+    if (comm_size) *comm_size = n;
+    if (comm_rank) *comm_rank = r;
+    if (rccl_version) *rccl_version = v;
+    return MCD_OK;
+}
 
 static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::unique_ptr<mcd_catalog>& cat);
 
@@ -725,8 +725,9 @@ static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::uni
     for (int i = 0; i < n_dev; ++i) {
         Shard& sh = cat->shards[i];
         sh.slot = i;
-        sh.star_begin = d->n_stars * i / n_dev;
-        sh.n = d->n_stars * (i + 1) / n_dev - sh.star_begin;
+        const mcd::ShardRange range = mcd::shard_range(d->n_stars, i, n_dev);
+        sh.star_begin = range.begin;
+        sh.n = range.n;
         const DeviceSlot& slot = ctx->slots[i];
         MCD_HIP(hipSetDevice(slot.device));
         MCD_HIP(hipEventCreate(&sh.ev_begin));
@@ -736,18 +737,7 @@ static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::uni
         MCD_HIP(hipMalloc(&sh.records, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256)));  // slack for wide scalar loads
         MCD_HIP(hipMemsetAsync(sh.records, 0, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256), slot.stream));
         if (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY) {
-            std::vector<double> sums(cat->n_psets, 0.0);
-            for (int64_t p = 0; p < cat->n_psets; ++p) {
-                const int64_t b0 = std::max(cat->bin_offsets[p], sh.star_begin);
-                const int64_t b1 = std::min(cat->bin_offsets[p + 1], sh.star_begin + sh.n);
-                double sum = 0.0, comp = 0.0;                       // Neumaier-compensated
-                for (int64_t i = b0; i < b1; ++i) {
-                    const double x = d->lnlike_bg[i], t = sum + x;
-                    comp += (std::fabs(sum) >= std::fabs(x)) ? (sum - t) + x : (x - t) + sum;
-                    sum = t;
-                }
-                sums[p] = sum + comp;
-            }
+            const std::vector<double> sums = mcd::pset_background_sums(d->lnlike_bg, cat->bin_offsets, sh.star_begin, sh.n);
             MCD_HIP(hipMalloc(&sh.d_pset_const, sums.size() * sizeof(double)));
             MCD_HIP(hipMemcpy(sh.d_pset_const, sums.data(), sums.size() * sizeof(double), hipMemcpyHostToDevice));
         }

@@ -1,0 +1,136 @@
+// mcd_chunks.h -- host-only planning of the work decomposition: star shards per device / rank and the chunk table of
+// one shard.  No HIP types here, so that the C-ABI (mcd_api.hip) and the CPU test harness (tests/emul) share exactly
+// the code that decides which stars a wave evaluates (as mcd_guard.h does for the range guard).
+//
+// Reference counterpart: none.  The reference evaluates all stars of one walker in one NumPy pass
+// (analysis/runner.py:261-286); its only parallelism is a process pool over walkers (runner.py:398-403).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace mcd {
+
+// One unit of work of the main kernel: a contiguous run of stars that all use parameter set `pset`.
+// A wave evaluates one chunk for 64 walkers (lane = walker; star records arrive through the scalar
+// cache as wave-uniform loads).
+struct Chunk {
+    int64_t begin;   // first star (record index on this device)
+    int32_t count;   // stars in the chunk
+    int32_t pset;    // parameter set (radial bin) the stars belong to
+};
+
+// Contiguous, balanced star range of shard `i` of `n_shards` (sizes differ by at most one); the same rule as
+// distributed.shard_bounds on the Python side.
+struct ShardRange { int64_t begin, n; };
+inline ShardRange shard_range(int64_t n_stars, int i, int n_shards) {
+    const int64_t b = n_stars * i / n_shards;
+    return ShardRange{b, n_stars * (i + 1) / n_shards - b};
+}
+
+constexpr int64_t kMaxChunkLen = (int64_t)1 << 20;      // keeps per-chunk exponent sums far inside int32 (mcd_math.h: LogProduct)
+
+struct ChunkPlan {
+    std::vector<Chunk> chunks;          // ascending star order; a parameter set's chunks are consecutive
+    std::vector<int64_t> offsets;       // [n_psets + 1] first chunk of each parameter set
+    std::vector<uint8_t> general;       // per chunk: holds a narrow_exception star (empty when no chunk does)
+    int64_t max_chunks_per_pset = 0;
+    int64_t len = 0;                    // nominal chunk length
+    int uniform_len = 0;                // > 0: chunk c covers records [c len, min((c + 1) len, n)) of parameter set 0
+};
+
+// Chunk table of the shard [star_begin, star_begin + n) of a catalogue whose parameter sets (radial bins) are the
+// global star ranges bin_offsets[p] .. bin_offsets[p + 1]; a bin that straddles the shard edge contributes its local
+// part (the partial sums of the shards add up in the all-reduce).
+//   * nominal length = roundup32(n n_wtiles / target_waves), at least 64: `target_waves` waves per launch
+//   * guided schedule (tail_split): workgroups are dispatched in chunk order, so the end of a large parameter set is
+//     cut into shorter chunks and the launch ends on short waves.  0 equal chunks; 1 = 85/10/5 % at len, len/2, len/4;
+//     2 = 70/15/10/5 % down to len/8; 3, 4 = guided self-scheduling, chunk = remaining work / (G x resident waves)
+//   * every chunk length is a multiple of 8 except the last chunk of a parameter set
+//   * narrow_exceptions: ascending GLOBAL star indices (mcd_guard.h)
+inline ChunkPlan plan_chunks(const std::vector<int64_t>& bin_offsets, int64_t star_begin, int64_t n, int64_t n_walkers,
+                             int64_t target_waves, int tail_split, const std::vector<int64_t>& narrow_exceptions) {
+    ChunkPlan plan;
+    const int64_t n_psets = (int64_t)bin_offsets.size() - 1;
+    const int64_t n_wtiles = (n_walkers + 63) / 64;
+    int64_t len = (n * n_wtiles + target_waves - 1) / std::max<int64_t>(1, target_waves);
+    len = std::max<int64_t>(64, (len + 31) / 32 * 32);          // quarter-length tail chunks stay multiples of 8
+    len = std::min(len, kMaxChunkLen);
+    plan.len = len;
+    plan.offsets.assign(n_psets + 1, 0);
+    for (int64_t p = 0; p < n_psets; ++p) {
+        plan.offsets[p] = (int64_t)plan.chunks.size();
+        const int64_t b0 = std::max(bin_offsets[p], star_begin);
+        const int64_t b1 = std::min(bin_offsets[p + 1], star_begin + n);
+        const int64_t total = b1 - b0;
+        const int mode = (total >= 16 * len && len >= 128) ? tail_split : 0;
+        const int64_t resident_chunks = std::max<int64_t>(1, 8192 / n_wtiles);
+        for (int64_t s = b0; s < b1;) {
+            const int64_t done = s - b0, rem = b1 - s;
+            int64_t step = len;
+            if (mode == 1) step = done * 100 < total * 85 ? len : (done * 100 < total * 95 ? len / 2 : len / 4);
+            else if (mode == 2) step = done * 100 < total * 70 ? len : (done * 100 < total * 85 ? len / 2 : (done * 100 < total * 95 ? len / 4 : len / 8));
+            else if (mode == 3) step = std::min(len, std::max<int64_t>(64, rem / (2 * resident_chunks) / 8 * 8));
+            else if (mode == 4) step = std::min(len, std::max<int64_t>(128, rem / resident_chunks / 8 * 8));
+            step = std::max<int64_t>(8, step / 8 * 8);
+            Chunk c;
+            c.begin = s - star_begin;
+            c.count = (int32_t)std::min(step, rem);
+            c.pset = (int32_t)p;
+            plan.chunks.push_back(c);
+            s += step;
+        }
+        plan.max_chunks_per_pset = std::max<int64_t>(plan.max_chunks_per_pset, (int64_t)plan.chunks.size() - plan.offsets[p]);
+    }
+    plan.offsets[n_psets] = (int64_t)plan.chunks.size();
+    if (n_psets == 1 && !plan.chunks.empty() && len < (int64_t)1 << 30) {
+        bool uniform = true;
+        for (size_t i = 0; i < plan.chunks.size() && uniform; ++i)
+            uniform = plan.chunks[i].begin == (int64_t)i * len &&
+                      plan.chunks[i].count == (int32_t)std::min<int64_t>(len, n - (int64_t)i * len);
+        if (uniform) plan.uniform_len = (int)len;
+    }
+    if (!narrow_exceptions.empty()) {
+        plan.general.assign(plan.chunks.size(), 0);
+        bool any = false;
+        for (size_t i = 0; i < plan.chunks.size(); ++i) {
+            const int64_t lo = star_begin + plan.chunks[i].begin, hi = lo + plan.chunks[i].count;
+            const auto it = std::lower_bound(narrow_exceptions.begin(), narrow_exceptions.end(), lo);
+            if (it != narrow_exceptions.end() && *it < hi) { plan.general[i] = 1; any = true; }
+        }
+        if (!any) plan.general.clear();
+    }
+    return plan;
+}
+
+// Walker-independent part of the fixed-background likelihoods: sum of lnL_bg over the shard's stars of each parameter
+// set (Neumaier-compensated).  Added once per output by the reduce kernel when a fast mixture kernel ran.
+inline std::vector<double> pset_background_sums(const double* lnlike_bg, const std::vector<int64_t>& bin_offsets,
+                                                int64_t star_begin, int64_t n) {
+    const int64_t n_psets = (int64_t)bin_offsets.size() - 1;
+    std::vector<double> sums(n_psets, 0.0);
+    for (int64_t p = 0; p < n_psets; ++p) {
+        const int64_t b0 = std::max(bin_offsets[p], star_begin);
+        const int64_t b1 = std::min(bin_offsets[p + 1], star_begin + n);
+        double sum = 0.0, comp = 0.0;
+        for (int64_t i = b0; i < b1; ++i) {
+            const double x = lnlike_bg[i], t = sum + x;
+            comp += (std::fabs(sum) >= std::fabs(x)) ? (sum - t) + x : (x - t) + sum;
+            sum = t;
+        }
+        sums[p] = sum + comp;
+    }
+    return sums;
+}
+
+// Grid of the main kernel for a chunk table (mcd_kernels.hip: loglike_kernel): up to 4 walker tiles share a workgroup;
+// beyond 256 walkers the workgroups of a chunk are dealt so that they share an XCD (groups of 8 chunks).
+inline int64_t main_grid(int64_t n_chunks, int64_t n_walkers) {
+    const int64_t n_wtiles = (n_walkers + 63) / 64;
+    if (n_wtiles <= 4) return (n_chunks * n_wtiles + 3) / 4;
+    return (n_chunks + 7) / 8 * 8 * ((n_wtiles + 3) / 4);
+}
+
+}  // namespace mcd

@@ -25,13 +25,13 @@ struct CatalogStats {
     bool narrow_possible = false;                   // at most 1/8 of the stars are exceptions (else: general form throughout)
 };
 
-// BGFIXED: a certain member (pmember == 1: the mixture value y = (1 - p) + ... has no floor) or lnL_bg < -150 (y can
-// exceed 2^250).  BGGAUSS family: density outside [2^-20, 2^20] (the undamped term rho g can vanish or explode).
-// PROFILE_BGDENS: lnL_bg < -120 or density > 2^20.
+// BGFIXED: a certain member (pmember == 1: the mixture value y = (1 - p) + ... has no floor) or lnL_bg < -60 (y can
+// exceed 2^120: eight raw factors no longer fit between two rescales).  BGGAUSS family: density outside [2^-20, 2^20]
+// (the undamped term rho g can vanish or explode).  PROFILE_BGDENS: lnL_bg < -45 or density > 2^20.
 inline bool narrow_exception(int bg, double lnbg, double pm, double rho) {
-    if (bg == BG_FIXED) return !(pm < 1.0) || lnbg < -150.0;
+    if (bg == BG_FIXED) return !(pm < 1.0) || lnbg < -60.0;
     if (bg == BG_GAUSS) return !(rho >= 0x1p-20 && rho <= 0x1p20);
-    if (bg == BG_FIXED_DENSITY) return lnbg < -120.0 || !(rho <= 0x1p20);
+    if (bg == BG_FIXED_DENSITY) return lnbg < -45.0 || !(rho <= 0x1p20);
     return false;
 }
 
@@ -169,8 +169,8 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
 
 // Launch level for mcd::LaunchShape::fast: 0 plain kernels, 1 fast formulation, 2 narrow-range variant (chunks that hold
 // a narrow_exception star still run the fast formulation of level 1).
-// BGFIXED (BgFixedAcc::add<.., NARROW>): pmember < 1 (so every mixture value y >= 1 - p >= 2^-53), lnlike_bg >= -150 and
-// norm >= 2^-60 (so y <= 1 + 2 norm^-1/2 e^150 < 2^250): four raw factors fit between rescales; |v - v_los|^2 <= 1e7 norm.
+// BGFIXED (BgFixedAcc::add<.., NARROW>): pmember < 1 (so every mixture value y >= 1 - p >= 2^-53), lnlike_bg >= -60 and
+// norm >= 2^-60 (so y <= 1 + norm^-1/2 e^60 < 2^120): eight raw factors fit between rescales; |v - v_los|^2 <= 2e6 norm.
 inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
                       int64_t n_rows) {
     GuardRanges g;
@@ -178,16 +178,16 @@ inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool 
     if (f32) return 1;
     const double lo = 0x1p-60, hi = 0x1p60;
     // Per-call conditions of the narrow-range variants (the per-star ones are CatalogStats::narrow_exceptions):
-    // d_max^2 <= 1e7 n_min keeps the exponent argument above -5e6, inside the int range of exp_tab without a clamp.
+    // d_max^2 <= 2e6 n_min keeps the exponent argument above -1.1e6, inside the int range of exp_tab (|u| < 1.4e6) without a clamp.
     if (!st.narrow_possible) return 1;
-    if (model == MODEL_BGFIXED && g.n_min >= lo && g.d_max * g.d_max <= 1.0e7 * g.n_min) return 2;
-    // BgFixedAcc::add_density<NARROW>: y = f + rho g e^u >= f >= 2^-20 and <= 2^20 + 2^20 2^31 e^120 < 2^225
+    if (model == MODEL_BGFIXED && g.n_min >= lo && g.d_max * g.d_max <= 2.0e6 * g.n_min) return 2;
+    // BgFixedAcc::add_density<NARROW>: y = f + rho g e^u >= f >= 2^-20 and <= 2^20 + 2^20 2^31 e^45 < 2^117 (eight factors per rescale)
     if (bg_kind(model) == BG_FIXED_DENSITY && g.f_min >= 0x1p-20 && g.f_max <= 0x1p20 && g.n_min >= lo &&
-        g.d_max * g.d_max <= 1.0e7 * g.n_min)
+        g.d_max * g.d_max <= 2.0e6 * g.n_min)
         return 2;
     // BgGaussAcc::add<.., NARROW>: y >= the undamped term min(rho g, f g_b) >= 2^-20 2^-31 and y <= (rho + f) 2^31 <= 2^52
     if (bg_kind(model) == BG_GAUSS && g.f_min >= 0x1p-20 && g.f_max <= 0x1p20 && g.n_min >= lo && g.n_max <= hi &&
-        g.nb_min >= lo && g.nb_max <= hi && g.d_max * g.d_max <= 1.0e7 * std::min(g.n_min, g.nb_min))
+        g.nb_min >= lo && g.nb_max <= hi && g.d_max * g.d_max <= 2.0e6 * std::min(g.n_min, g.nb_min))
         return 2;
     return 1;
 }

@@ -4,16 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
-namespace mcd {
+#include "mcd_chunks.h"   // Chunk, chunk-table planning (host-only, shared with the CPU tests)
 
-// One unit of work of the main kernel: a contiguous run of stars that all use parameter set `pset`.
-// A wave evaluates one chunk for 64 walkers (lane = walker; star records arrive through the scalar
-// cache as wave-uniform loads).
-struct Chunk {
-    int64_t begin;   // first star (record index on this device)
-    int32_t count;   // stars in the chunk
-    int32_t pset;    // parameter set (radial bin) the stars belong to
-};
+namespace mcd {
 
 struct LaunchShape {
     int model;        // mcd::Model
@@ -49,7 +42,8 @@ hipError_t launch_prepare_walkers(hipStream_t s, const double* params, int64_t n
 hipError_t launch_loglike(hipStream_t s, const LaunchShape& shape, const void* records, const Chunk* chunks,
                           int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers);
 
-// out[pset][w] = sum over the chunks of pset of partials[w][chunk]  (fixed order) [+ pset_const[pset]]
+// out[pset][w] = sum over the chunks of pset of partials[w / 8][chunk][w % 8]  (fixed order) [+ pset_const[pset]];
+// `partials` holds roundup64(n_walkers) x n_chunks doubles
 hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* pset_chunk_offsets,
                          int64_t n_psets, int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers,
                          const double* pset_const, double* out);

@@ -32,8 +32,9 @@ __global__ __launch_bounds__(kBlock) void kde_slice_kernel(const double* __restr
                                                             double* __restrict__ part_dmin,
                                                             double* __restrict__ part_sum) {
     __shared__ double exptab[kExpTabSize];
-    static_assert(kExpTabSize == kBlock, "one table entry per thread");
-    exptab[threadIdx.x] = kExpTabDevice[threadIdx.x];
+    static_assert(kExpTabSize % kBlock == 0, "whole table entries per thread");
+#pragma unroll
+    for (int i = 0; i < kExpTabSize / kBlock; ++i) exptab[i * kBlock + threadIdx.x] = kExpTabDevice[i * kBlock + threadIdx.x];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);

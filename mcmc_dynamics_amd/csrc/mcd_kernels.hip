@@ -6,8 +6,9 @@
 //     (scalar cache, broadcast to all lanes for free as SGPR operands of the f64 VALU ops), so one
 //     32..64-byte record load feeds 64 star-walker terms and no LDS/VGPR staging is spent on it.
 //   * each wave keeps its walkers' running sums in registers; no cross-lane traffic in the hot loop.
-//   * per-(walker, chunk) partials go to HBM; a second kernel reduces them with a fixed tree
-//     (wave shuffle + LDS), so results are bitwise reproducible.  No float atomics anywhere.
+//   * per-(walker, chunk) partials go to HBM as partials[walker / 8][chunk][walker % 8] (a wave's store is eight
+//     full 64-byte segments); a second kernel reduces them with a fixed tree (wave shuffle + LDS), so results are
+//     bitwise reproducible.  No float atomics anywhere.
 //
 // The kernel is bound by the f64 VALU issue rate, not by HBM: the catalogue (32..64 B/star) is read
 // once per 64..256 walkers.  MFMA has nothing to offer here (no contraction).
@@ -21,6 +22,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;               // 4 waves: one per SIMD of a CU
 constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kPartialGroup = 8;            // walkers per group of the partial-sum array (8 doubles = one 64-byte segment)
 
 constexpr double kDeg2Rad = 0.017453292519943295769;
 constexpr double kR0Arcmin = 3437.7467707849392526;   // 10800 / pi, calc_xy_offset.py:11
@@ -67,14 +69,14 @@ __global__ __launch_bounds__(kBlock) void prepare_records_kernel(RawColumns raw,
     const int bg = bg_kind(model);
     if (bg == BG_FIXED) {
         // fast paths: exponent offset with the prior weight folded in, log p - (b + 1/2 log 2pi); the floor keeps it finite
-        // for p == 0 (e^-1e5 is an exact 0 in f64, so y = 1 - p exactly as it must)
+        // for p == 0 (e^-2000 is an exact 0 in f64, so y = 1 - p exactly as it must)
         const double b = raw.lnbg[i], pm = raw.pmember[i];
-        r[k] = (T)b; r[k + 1] = (T)pm; r[k + 2] = (T)(1.0 - pm); r[k + 3] = (T)fmax(log(pm) - (b + kHalfLn2Pi), -1.0e5);
+        r[k] = (T)b; r[k + 1] = (T)pm; r[k + 2] = (T)(1.0 - pm); r[k + 3] = (T)fmax(log(pm) - (b + kHalfLn2Pi), -2000.0);
     } else if (bg == BG_GAUSS) {
         r[k] = (T)raw.density[i]; r[k + 1] = (T)0;
     } else if (bg == BG_FIXED_DENSITY) {
         const double b = raw.lnbg[i];
-        r[k] = (T)b; r[k + 1] = (T)fmax(log(raw.density[i]) - (b + kHalfLn2Pi), -1.0e5); r[k + 2] = (T)raw.density[i];
+        r[k] = (T)b; r[k + 1] = (T)fmax(log(raw.density[i]) - (b + kHalfLn2Pi), -2000.0); r[k + 2] = (T)raw.density[i];
         r[k + 3] = (T)0;
     }
 }
@@ -130,12 +132,14 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
                                                           double* __restrict__ rerun_flag, double launch_tag,
                                                           const uint8_t* __restrict__ chunk_general) {
     constexpr int ND = record_doubles(MODEL, FREE);
-    // fast mixtures: the 2^(j/256) table of exp_tab lives in LDS (2 KiB), one entry copied per thread
+    // fast mixtures: the 2^(j/1024) table of exp_tab lives in LDS (8 KiB per workgroup), four entries copied per thread
     constexpr bool kUsesExpTab = FAST && bg_kind(MODEL) != BG_NONE && sizeof(T) == 8;
     __shared__ double exptab_lds[kUsesExpTab ? kExpTabSize : 1];
     if constexpr (kUsesExpTab) {
-        static_assert(kExpTabSize == kBlock, "one table entry per thread");
-        exptab_lds[threadIdx.x] = exp_table_is_sqrt2_scaled(MODEL) ? kExpTabSqrt2Device[threadIdx.x] : kExpTabDevice[threadIdx.x];
+        static_assert(kExpTabSize % kBlock == 0, "whole table entries per thread");
+        const double* __restrict__ src = exp_table_is_sqrt2_scaled(MODEL) ? kExpTabSqrt2Device : kExpTabDevice;
+#pragma unroll
+        for (int i = 0; i < kExpTabSize / kBlock; ++i) exptab_lds[i * kBlock + threadIdx.x] = src[i * kBlock + threadIdx.x];
         __syncthreads();
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -199,60 +203,56 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
         if (rerun_flag) *rerun_flag = launch_tag;
         else result = __builtin_nan("");
     }
-    if (active) partials[w_raw * n_chunks + chunk_id] = result;
+    // partials[walker group of 8][chunk][walker in group]: eight full 64-byte segments per wave store (the rows are
+    // padded to whole walker tiles, so idle lanes store their shadow value into padding), and the reduce kernel streams
+    // one contiguous [chunk][8] block per walker group.
+    partials[((w_raw >> 3) * n_chunks + chunk_id) * kPartialGroup + (w_raw & (kPartialGroup - 1))] = result;
 }
 
 // ------------------------------------------------------------------------------------------------
-// final reduction, wide form: one 256-thread block per output (pset, walker); contiguous partials
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-    return x;
-}
-
-__global__ __launch_bounds__(kBlock) void reduce_wide_kernel(const double* __restrict__ partials,
-                                                              const int64_t* __restrict__ offs, int64_t n_chunks,
-                                                              int64_t n_walkers, const double* __restrict__ pset_const,
-                                                              double* __restrict__ out) {
-    __shared__ double lds[kWavesPerBlock];
-    const int64_t o = blockIdx.x;
-    const int64_t pset = o / n_walkers, w = o - pset * n_walkers;
+// final reduction: one block per (parameter set, group of 8 walkers).  The group's partial sums are one contiguous
+// [chunk][8] array; thread t = (sublane s = t / 8, walker j = t % 8) adds the chunks c0 + s, c0 + s + SUB, ... in
+// four interleaved accumulators (four loads in flight), the SUB sublanes are combined by a wave shuffle tree and a
+// fixed-order sum over the waves: the order of every addition is fixed by (n_chunks, SUB) alone -- bitwise repeatable.
+template <int SUB>
+__global__ __launch_bounds__(kPartialGroup * SUB) void reduce_group_kernel(const double* __restrict__ partials,
+                                                                            const int64_t* __restrict__ offs,
+                                                                            int64_t n_chunks, int64_t n_walkers,
+                                                                            int64_t n_groups,
+                                                                            const double* __restrict__ pset_const,
+                                                                            double* __restrict__ out) {
+    constexpr int kThreads = kPartialGroup * SUB;
+    constexpr int kWaves = kThreads / kWave;
+    __shared__ double lds[kWaves > 1 ? kWaves : 1][kPartialGroup];
+    const int64_t pset = blockIdx.x / n_groups, g = blockIdx.x - pset * n_groups;
+    const int j = threadIdx.x & (kPartialGroup - 1), s = threadIdx.x >> 3;
     const int64_t c0 = offs[pset], c1 = offs[pset + 1];
-    const double* __restrict__ row = partials + w * n_chunks;
-    // four independent accumulators per thread keep four loads in flight (fixed order: bitwise repeatable)
+    const double* __restrict__ col = partials + g * n_chunks * kPartialGroup + j;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int64_t c = c0 + threadIdx.x;
-    for (; c + 3 * kBlock < c1; c += 4 * kBlock) {
-        a0 += row[c];
-        a1 += row[c + kBlock];
-        a2 += row[c + 2 * kBlock];
-        a3 += row[c + 3 * kBlock];
+    int64_t c = c0 + s;
+    for (; c + 3 * SUB < c1; c += 4 * SUB) {
+        a0 += col[c * kPartialGroup];
+        a1 += col[(c + SUB) * kPartialGroup];
+        a2 += col[(c + 2 * SUB) * kPartialGroup];
+        a3 += col[(c + 3 * SUB) * kPartialGroup];
     }
-    for (; c < c1; c += kBlock) a0 += row[c];
+    for (; c < c1; c += SUB) a0 += col[c * kPartialGroup];
     double acc = (a0 + a1) + (a2 + a3);
-    acc = wave_sum(acc);
-    if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double c = pset_const ? pset_const[pset] : 0.0;     // walker-independent part (sum of lnL_bg)
-        out[o] = ((lds[0] + lds[1]) + (lds[2] + lds[3])) + c;
+    // the 8 sublanes of a wave: lanes j, j + 8, ..., j + 56
+#pragma unroll
+    for (int off = 32; off >= kPartialGroup; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if constexpr (kWaves > 1) {
+        if ((threadIdx.x & (kWave - 1)) < kPartialGroup) lds[threadIdx.x >> 6][j] = acc;
+        __syncthreads();
+        if (threadIdx.x < kPartialGroup) {
+            acc = lds[0][j];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) acc += lds[w][j];
+        }
     }
-}
-
-// narrow form: one thread per output, few chunks per parameter set (radial bins)
-__global__ __launch_bounds__(kBlock) void reduce_narrow_kernel(const double* __restrict__ partials,
-                                                                const int64_t* __restrict__ offs, int64_t n_psets,
-                                                                int64_t n_chunks, int64_t n_walkers,
-                                                                const double* __restrict__ pset_const,
-                                                                double* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= n_psets * n_walkers) return;
-    const int64_t w = t / n_psets, pset = t - w * n_psets;       // pset fastest: neighbouring chunks
-    const int64_t c0 = offs[pset], c1 = offs[pset + 1];
-    const double* __restrict__ row = partials + w * n_chunks;
-    double acc = 0.0;
-    for (int64_t c = c0; c < c1; ++c) acc += row[c];
-    out[pset * n_walkers + w] = acc + (pset_const ? pset_const[pset] : 0.0);
+    const int64_t w = g * kPartialGroup + j;
+    if (threadIdx.x < kPartialGroup && w < n_walkers)
+        out[pset * n_walkers + w] = acc + (pset_const ? pset_const[pset] : 0.0);   // walker-independent part (sum of lnL_bg)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -283,9 +283,7 @@ hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, i
                       double launch_tag, const uint8_t* chunk_general) {
     const int n_wtiles = (int)((n_walkers + kWave - 1) / kWave);
     const int64_t n_tasks = n_chunks * n_wtiles;
-    int64_t grid = (n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (n_wtiles > kWavesPerBlock)                         // XCD-aware grouping, see loglike_kernel
-        grid = (n_chunks + 7) / 8 * 8 * ((n_wtiles + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int64_t grid = main_grid(n_chunks, n_walkers);   // > 256 walkers: XCD-aware grouping, see loglike_kernel
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST>), dim3((unsigned)grid), dim3(kBlock), 0, s,
                        (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,
@@ -379,16 +377,20 @@ hipError_t launch_loglike(hipStream_t s, const LaunchShape& sh, const void* reco
 hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* offs, int64_t n_psets,
                          int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers, const double* pset_const,
                          double* out) {
-    const int64_t n_out = n_psets * n_walkers;
-    if (n_out <= 0) return hipSuccess;
-    if (max_chunks_per_pset > 16) {
-        hipLaunchKernelGGL(reduce_wide_kernel, dim3((unsigned)n_out), dim3(kBlock), 0, s, partials, offs, n_chunks,
-                           n_walkers, pset_const, out);
-    } else {
-        const unsigned grid = (unsigned)((n_out + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(reduce_narrow_kernel, dim3(grid), dim3(kBlock), 0, s, partials, offs, n_psets, n_chunks,
-                           n_walkers, pset_const, out);
-    }
+    if (n_psets * n_walkers <= 0) return hipSuccess;
+    const int64_t n_groups = (n_walkers + kPartialGroup - 1) / kPartialGroup;
+    const dim3 grid((unsigned)(n_psets * n_groups));
+    // sublanes per walker group by the longest parameter set: 128 (1024 threads) streams ~28 chunks per thread at
+    // C3's 3551 chunks; radial bins with a few chunks each take one wave per group
+    if (max_chunks_per_pset > 512)
+        hipLaunchKernelGGL(reduce_group_kernel<128>, grid, dim3(kPartialGroup * 128), 0, s, partials, offs, n_chunks,
+                           n_walkers, n_groups, pset_const, out);
+    else if (max_chunks_per_pset > 32)
+        hipLaunchKernelGGL(reduce_group_kernel<32>, grid, dim3(kPartialGroup * 32), 0, s, partials, offs, n_chunks,
+                           n_walkers, n_groups, pset_const, out);
+    else
+        hipLaunchKernelGGL(reduce_group_kernel<8>, grid, dim3(kPartialGroup * 8), 0, s, partials, offs, n_chunks,
+                           n_walkers, n_groups, pset_const, out);
     return hipGetLastError();
 }
 

@@ -188,6 +188,17 @@ struct LogProduct {
         e += (int64_t)(e32 + ex);
         e32 = 0;
     }
+    // narrow-range products: the group exponent stays in the 32-bit counter (|ex| <= 1000 per group of up to 8 factors,
+    // chunks hold <= 2^20 stars: mcd_chunks.h kMaxChunkLen), folded into e by value()
+    MCD_HD void rescale_narrow() {
+        int ex;
+#if defined(__HIP_DEVICE_COMPILE__)
+        p = __builtin_frexp(p, &ex);
+#else
+        p = std::frexp(p, &ex);
+#endif
+        e32 += ex;
+    }
     MCD_HD void mul_any(double x) {                  // any positive finite x: split first
         int ex;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -392,13 +403,31 @@ MCD_HD double rcp_nr(double x) {
     return fma_(y, fma_(e, e, e), y);
 }
 
-// e^u = 2^e T[j] e^r with k = rint(u 256 / ln 2) = 256 e + j, |r| <= ln 2 / 512, T[j] = 2^(j/256)
-// (mcd_exp_table.h, correctly rounded).  Degree-4 Taylor polynomial on that interval: remainder r^5/120 <= 3.8e-17.
-// Returns the mantissa part T[j] e^r in [1, 2) and e.  `tab` points to the 256-entry table: LDS on the device (each
-// workgroup copies it there; the per-lane lookup is a ds_read, off the VALU), a static array on the host.
-// k comes out of the low word of u * (256 / ln 2) + 1.5 * 2^52 (round-to-nearest-even), so no v_rndne / v_cvt.
-// Requires |u| < 2^21 (callers clamp or are bounded by the host guard).  About 5 f64 VALU fewer than a table-free
-// degree-11 polynomial on |r| <= ln 2 / 2 (measured: BGFIXED 327 -> see DESIGN.md section 3.2).
+// 2 m^(-1/2) from v_rsq_f64 and ONE Newton step in its three-instruction form,  y (3 - m y^2) = 2 y (1 + e/2),
+// e = 1 - m y^2 (|e| <= 2^-23.2):  m^-1/2 = y (1 + e/2 + 3 e^2/8 + ...), so the result is low by 3/8 e^2 <= 4.1e-15
+// relative (1.4e-15 on average) plus three roundings.  Used by the narrow-range mixture variants only, where a term's
+// log-likelihood responds to that factor with a sensitivity <= |1 - d^2/n|: over N stars the sum moves by <= 4e-15 N,
+// i.e. 1e-15 of |lnL| -- inside the rounding error of the reference's own float64 summation.  The factor 2 is free:
+// callers scale the variance they pass (m = 8 n gives (2 n)^-1/2).  Two instructions fewer than rsqrt_nr.
+MCD_HD double rsqrt2_newton(double m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(m);
+#else
+    const double y = 1.0 / std::sqrt(m);
+#endif
+    const double s = fma_(-m, y * y, 3.0);
+    return y * s;
+}
+
+// e^u = 2^e T[j] e^r with k = rint(u N / ln 2) = N e + j, |r| <= ln 2 / 2N, T[j] = 2^(j/N) (mcd_exp_table.h,
+// correctly rounded).  N = 1024 (default build): degree-3 polynomial 1 + r + c2 r^2 + c3 r^3 with the even part of its
+// error levelled by c2 (tools/gen_exp_table.py), max error 9.4e-17, i.e. below half an ulp -- one FMA per term fewer than
+// N = 256 with the degree-4 Taylor polynomial (remainder 3.8e-17; -DMCD_EXP_TAB_BITS=8), for one more integer
+// instruction (the 8-bit index is a byte select, the 10-bit one an and + shift).
+// Returns the mantissa part T[j] e^r in [1, 2) and e.  `tab` points to the table: LDS on the device (each workgroup
+// copies it there; the per-lane lookup is a ds_read_b64, off the VALU), a static array on the host.
+// k comes out of the low word of u * (N / ln 2) + 1.5 * 2^52 (round-to-nearest-even), so no v_rndne / v_cvt.
+// Requires |u| < 1.4e6 (k inside int32; callers clamp or are bounded by the host guard, mcd_guard.h).
 template <bool TWO_STEP = true>
 MCD_HD double exp_tab(double u, int& e_out, const double* __restrict__ tab) {
     constexpr double kMagic = 6755399441055744.0;            // 1.5 * 2^52
@@ -412,12 +441,13 @@ MCD_HD double exp_tab(double u, int& e_out, const double* __restrict__ tab) {
         r = fma_(-kf, kExpTabStepHi, u);
         r = fma_(-kf, kExpTabStepLo, r);
     } else {
-        // one-constant reduction: ln 2 / 256 rounded to f64 is off by < 2.2e-19, so r is off by < 2.2e-19 |k|, i.e. a
-        // relative error of 8e-17 |u| in e^u -- for callers whose |u| is small wherever e^u matters
+        // one-constant reduction: ln 2 / N rounded to f64 is off by < 2^-53 of itself, so r is off by < 1.1e-16 |k| ln 2 / N,
+        // i.e. a relative error of 8e-17 |u| in e^u -- for callers whose |u| is small wherever e^u matters
         r = fma_(-kf, kExpTabStepHi + kExpTabStepLo, u);
     }
-    double p = fma_(r, 1.0 / 24.0, 1.0 / 6.0);
-    p = fma_(p, r, 0.5);
+    double p;
+    if constexpr (kExpPolyDegree == 4) p = fma_(fma_(r, kExpPolyC4, kExpPolyC3), r, kExpPolyC2);
+    else p = fma_(r, kExpPolyC3, kExpPolyC2);
     p = fma_(p, r, 1.0);
     p = fma_(p, r, 1.0);
     e_out = k >> kExpTabBits;
@@ -484,20 +514,22 @@ struct BgFixedAcc {
     // HALVED: the caller passes 2 n instead of n and the table sqrt(2) 2^(j/256) (MCD_EXP_TABLE_SQRT2_VALUES):
     //   gh = (2 n)^(-1/2) = g / sqrt(2),  -(d gh)^2 = -1/2 d^2 g^2,  p gh (sqrt(2) T[j]) e^r = p g T[j] e^r,
     // which drops the multiplication by -1/2 (2 n = 2 verr^2 + 2 sigma^2 is formed by one FMA, like n by one add).
-    // NARROW (chosen per call by the host guard, mcd_guard.h: fast_level): every y_i is known to lie in [2^-53, 2^250]
-    // -- pmember < 1 everywhere, so y >= 1 - p >= 2^-53; lnL_bg >= -150 and norm >= 2^-60, so y <= 1 + 2 g e^{150} --
-    // hence four raw factors can be multiplied between two rescales without the per-star mantissa/exponent split,
-    // without the k > 1000 exponent carry and without the denormal-regime tracking (7 VALU instructions per term less).
+    // NARROW (chosen per call by the host guard, mcd_guard.h: fast_level): every y_i is known to lie in [2^-53, 2^120]
+    // -- pmember < 1 everywhere, so y >= 1 - p >= 2^-53; lnL_bg >= -60 and norm >= 2^-60, so y <= 1 + 2^30 e^{60} --
+    // hence eight raw factors can be multiplied between two rescales without the per-star mantissa/exponent split,
+    // without the k > 1000 exponent carry and without the denormal-regime tracking; g comes from the one-step Newton
+    // form (rsqrt2_newton).
     template <bool UNIFORM_OMP = true, bool HALVED = false, bool NARROW = false>
     // The prior weight p of the cluster component is folded into the exponent by the record preparation:
-    // nbp = -(b + 1/2 log 2pi) + log p (floored at -1e5, where e^u is an exact 0: p == 0 gives y = 1 - p = 1), so
+    // nbp = -(b + 1/2 log 2pi) + log p (floored at -2000, where e^u is an exact 0: p == 0 gives y = 1 - p = 1), so
     // y = (1 - p) + g e^{u} with u = -1/2 d^2 g^2 + nbp needs no multiplication by p.
     MCD_HD void add(double d, double n, double omp, double nbp, const double* __restrict__ exptab) {
-        const double g = rsqrt_nr(n);
+        // NARROW + HALVED: the caller passes 8 n and the one-step Newton form returns 2 (8 n)^-1/2 = (2 n)^-1/2
+        const double g = (NARROW && HALVED) ? rsqrt2_newton(n) : rsqrt_nr(n);
         const double dg = d * g;
         // u <= 1e5 by the host guard (|lnL_bg| <= 1e5); below -1100 e^u is an exact 0 in f64 (as in the reference),
-        // and the clamp keeps 256 u / ln 2 inside the int range of exp_tab.
-        // (NARROW: the guard bounds |v - v_los|^2 / norm by 1e7, so u > -5e6 needs no clamp)
+        // and the clamp keeps u N / ln 2 inside the int range of exp_tab.
+        // (NARROW: the guard bounds |v - v_los|^2 / norm by 2e6 and the record floors nbp at -2000, so u > -1.1e6 needs no clamp)
         const double u0 = HALVED ? fnma_sgpr_addend(dg, dg, nbp) : fma_sgpr_addend(-0.5 * dg, dg, nbp);
         const double u = NARROW ? u0 : fmax_raw(u0, -1100.0);
         int k;
@@ -518,6 +550,8 @@ struct BgFixedAcc {
     }
     MCD_HD void rescale() { l.rescale(); }
     MCD_HD void rescale_density() { l.rescale(); lden.rescale(); }
+    MCD_HD void rescale_narrow() { l.rescale_narrow(); }
+    MCD_HD void rescale_density_narrow() { l.rescale_narrow(); lden.rescale_narrow(); }
     MCD_HD double finish() { return l.value(); }
     MCD_HD double finish_density() { return l.value() - lden.value(); }
 };
@@ -538,11 +572,13 @@ struct BgGaussAcc {
     //   -|wb/2 - w/2| = -delta needs no multiplication by -1/2; y comes out divided by sqrt(2) and min(w, wb) halved,
     //   both undone by constants in finish().
     // NARROW (host guard, mcd_guard.h: fast_level): density and f_back in [2^-20, 2^20], norms in [2^-60, 2^60], so
-    //   y >= the undamped term >= 2^-51 and y <= 2^52 -- four raw factors between rescales, no mantissa/exponent split,
-    //   no denormal tracking; |d|^2 <= 1e7 norm, so the exponent argument needs no clamp; one-constant range reduction.
+    //   y >= the undamped term >= 2^-51 and y <= 2^52 -- eight raw factors between rescales, no mantissa/exponent split,
+    //   no denormal tracking; |d|^2 <= 2e6 norm, so the exponent argument needs no clamp; one-constant range reduction.
     template <bool HALVED = false, bool NARROW = false>
     MCD_HD void add(double d, double n, double db, double nb, double rho, double f, const double* __restrict__ exptab) {
-        const double g = rsqrt_nr(n), gb = rsqrt_nr(nb);
+        // NARROW + HALVED: the caller passes 8 n and 8 nb (one-step Newton form, see BgFixedAcc::add)
+        const double g = (NARROW && HALVED) ? rsqrt2_newton(n) : rsqrt_nr(n);
+        const double gb = (NARROW && HALVED) ? rsqrt2_newton(nb) : rsqrt_nr(nb);
         const double dg = d * g, dbg = db * gb;
         const double w = dg * dg, wb = dbg * dbg;
         const double t = wb - w;
@@ -561,6 +597,7 @@ struct BgGaussAcc {
         sum_min += fmin_(w, wb);
     }
     MCD_HD void rescale() { ly.rescale(); lden.rescale(); }
+    MCD_HD void rescale_narrow() { ly.rescale_narrow(); lden.rescale_narrow(); }
     template <bool HALVED = false>
     MCD_HD double finish(int64_t count) {
         // HALVED: log y = log(y / sqrt 2) + 1/2 log 2 per star, and sum_min already carries its factor 1/2
@@ -751,29 +788,42 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         }
         result = -0.5 * ((double)count * kLn2Pi + (double)sum_log + (double)sum_q);
     } else if constexpr (BG == BG_FIXED && FAST) {
-        // MODEL_BGFIXED has norm = verr^2 + sigma^2 (constant.py:52-74): the accumulator takes 2 norm (HALVED form) and
-        // `exptab` is then the sqrt(2)-scaled table; star_d_n's own norm is dead code there.
+        // MODEL_BGFIXED has norm = verr^2 + sigma^2 (constant.py:52-74): the accumulator takes 2 norm (HALVED form; 8 norm
+        // for the narrow-range variant's one-step Newton reciprocal root) and `exptab` is then the sqrt(2)-scaled table;
+        // star_d_n's own norm is dead code there.
         constexpr bool HALVED = MODEL == MODEL_BGFIXED;
         constexpr bool NARROW = FAST == 2 && MODEL == MODEL_BGFIXED;
-        const double s2x2 = (double)w.s2 + (double)w.s2;
+        constexpr double kScale = NARROW ? 8.0 : 2.0;
+        const double s2x = kScale * (double)w.s2;
         BgFixedAcc acc;
         acc.init();
-        const int n4 = count >> 2;
-        for (int g = 0; g < n4; ++g, r += 4 * ND) {
+        auto four = [&](const double* __restrict__ r4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const double* rr = r + j * ND;
+                const double* rr = r4 + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
-                if constexpr (HALVED) n = fma_(2.0, rr[1], s2x2);
+                if constexpr (HALVED) n = fma_(kScale, rr[1], s2x);
                 acc.add<true, HALVED, NARROW>(d, n, rr[XB + 2], rr[XB + 3], exptab);
             }
-            acc.rescale();
+        };
+        const int n4 = count >> 2;
+        if constexpr (NARROW) {
+            // eight raw factors per rescale: two 4-star groups (one scalar record-load batch each) between rescales
+            const int n8 = n4 >> 1;
+            for (int g = 0; g < n8; ++g) {
+#pragma nounroll
+                for (int h = 0; h < 2; ++h, r += 4 * ND) four(r);
+                acc.rescale_narrow();
+            }
+            if (n4 & 1) { four(r); r += 4 * ND; acc.rescale_narrow(); }
+        } else {
+            for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale(); }
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(r, w, d, n);
-            if constexpr (HALVED) n = fma_(2.0, r[1], s2x2);
+            if constexpr (HALVED) n = fma_(kScale, r[1], s2x);
             acc.add<true, HALVED, NARROW>(d, n, r[XB + 2], r[XB + 3], exptab);
             acc.rescale();
         }
@@ -783,16 +833,26 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         constexpr bool NARROW = FAST == 2;          // f_back >= 2^-20 bounds every mixture value from below (mcd_guard.h)
         BgFixedAcc acc;
         acc.init();
-        const int n4 = count >> 2;
-        for (int g = 0; g < n4; ++g, r += 4 * ND) {
+        auto four = [&](const double* __restrict__ r4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const double* rr = r + j * ND;
+                const double* rr = r4 + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
                 acc.add_density<NARROW>(d, n, rr[XB + 2], w.fb, rr[XB + 1], exptab);
             }
-            acc.rescale_density();
+        };
+        const int n4 = count >> 2;
+        if constexpr (NARROW) {
+            const int n8 = n4 >> 1;
+            for (int g = 0; g < n8; ++g) {
+#pragma nounroll
+                for (int h = 0; h < 2; ++h, r += 4 * ND) four(r);
+                acc.rescale_density_narrow();
+            }
+            if (n4 & 1) { four(r); r += 4 * ND; acc.rescale_density_narrow(); }
+        } else {
+            for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale_density(); }
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
@@ -803,29 +863,38 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         result = acc.finish_density();
         denormal = acc.denormal();
     } else if constexpr (BG == BG_GAUSS && FAST) {
-        // MODEL_BGGAUSS has norm = verr^2 + sigma^2 and verr^2 + sigma_back^2: doubled norms are one FMA each (HALVED form)
+        // MODEL_BGGAUSS has norm = verr^2 + sigma^2 and verr^2 + sigma_back^2: doubled norms are one FMA each (HALVED form;
+        // 8 norm for the narrow-range variant's one-step Newton reciprocal roots)
         constexpr bool HALVED = MODEL == MODEL_BGGAUSS;
         constexpr bool NARROW = FAST == 2;
-        const double s2x2 = (double)w.s2 + (double)w.s2, sb2x2 = (double)w.sb2 + (double)w.sb2;
+        constexpr double kScale = NARROW ? 8.0 : 2.0;
+        const double s2x = kScale * (double)w.s2, sb2x = kScale * (double)w.sb2;
         BgGaussAcc acc;
         acc.init();
-        const int n4 = count >> 2;
-        for (int g = 0; g < n4; ++g, r += 4 * ND) {
+        auto one = [&](const double* __restrict__ rr) {
+            double d, n;
+            star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
+            if constexpr (HALVED) acc.add<true, NARROW>(d, fma_(kScale, rr[1], s2x), rr[0] - w.vb, fma_(kScale, rr[1], sb2x), rr[XB], w.fb, exptab);
+            else acc.add<false, NARROW>(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb, exptab);
+        };
+        auto four = [&](const double* __restrict__ r4) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double* rr = r + j * ND;
-                double d, n;
-                star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
-                if constexpr (HALVED) acc.add<true, NARROW>(d, fma_(2.0, rr[1], s2x2), rr[0] - w.vb, fma_(2.0, rr[1], sb2x2), rr[XB], w.fb, exptab);
-                else acc.add<false, NARROW>(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb, exptab);
+            for (int j = 0; j < 4; ++j) one(r4 + j * ND);
+        };
+        const int n4 = count >> 2;
+        if constexpr (NARROW) {
+            const int n8 = n4 >> 1;
+            for (int g = 0; g < n8; ++g) {
+#pragma nounroll
+                for (int h = 0; h < 2; ++h, r += 4 * ND) four(r);
+                acc.rescale_narrow();
             }
-            acc.rescale();
+            if (n4 & 1) { four(r); r += 4 * ND; acc.rescale_narrow(); }
+        } else {
+            for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale(); }
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
-            double d, n;
-            star_d_n<MODEL, double, FREE, true>(r, w, d, n);
-            if constexpr (HALVED) acc.add<true, NARROW>(d, fma_(2.0, r[1], s2x2), r[0] - w.vb, fma_(2.0, r[1], sb2x2), r[XB], w.fb, exptab);
-            else acc.add<false, NARROW>(d, n, r[0] - w.vb, r[1] + w.sb2, r[XB], w.fb, exptab);
+            one(r);
             acc.rescale();
         }
         result = acc.finish<HALVED>(count);

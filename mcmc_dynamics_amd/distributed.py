@@ -6,8 +6,9 @@ and every batched evaluation ends in ONE RCCL all-reduce (sum, f64) of the per-w
 log-likelihoods (``W`` doubles; ``B x W`` for a binned catalogue) inside ``libmcd_hip.so``.  The reference
 has no counterpart: its only parallelism is a process pool over walkers (runner.py:398-403).
 
-The host-side group (any ``torch.distributed`` backend, gloo is enough) is used only to hand rank 0's
-RCCL unique id to the other ranks.
+The host side only hands rank 0's 128-byte RCCL unique id to the other ranks (and, for ``Runner``, the start
+positions and the sampler seed): that goes over ``hostgroup.HostGroup`` -- plain TCP, no PyTorch anywhere in the
+package, so every process keeps the ROCm runtime and RCCL the library was built against.
 """
 import os
 
@@ -39,12 +40,11 @@ def shard_bin_offsets(bin_offsets, rank, world):
     return np.clip(offs, lo, hi) - lo
 
 
-def replicated_loglike(loglike_fn, params, rank=None, world=None, process_group=None):
+def replicated_loglike(loglike_fn, params, rank=None, world=None, group=None):
     """The other axis ("replicas"): every rank holds the FULL catalogue and evaluates only its
-    contiguous slice of the walkers; the slices are exchanged over the host process group (no device collective).  For
-    catalogues too small to fill several GPUs.  ``loglike_fn((w, K)) -> (w,)``; returns the complete ``(W,)`` on every rank."""
-    import torch
-    import torch.distributed as dist
+    contiguous slice of the walkers; the slices are exchanged over the host group (no device collective).  For
+    catalogues too small to fill several GPUs.  ``loglike_fn((w, K)) -> (w,)``; returns the complete ``(W,)`` on every
+    rank.  ``group``: a ``hostgroup.HostGroup`` (created from the environment when omitted and world > 1)."""
     if rank is None or world is None:
         rank, world, _ = env_rank()
     params = np.asarray(params, dtype=np.float64)
@@ -52,13 +52,9 @@ def replicated_loglike(loglike_fn, params, rank=None, world=None, process_group=
     mine = np.asarray(loglike_fn(params[lo:hi]), dtype=np.float64) if hi > lo else np.empty(0)
     if world == 1:
         return mine
-    sizes = [shard_bounds(len(params), r, world) for r in range(world)]
-    width = max(h - l for l, h in sizes)
-    padded = torch.zeros(width, dtype=torch.float64)
-    padded[:hi - lo] = torch.from_numpy(mine)
-    parts = [torch.zeros(width, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(parts, padded, group=process_group)
-    return np.concatenate([parts[r][:h - l].numpy() for r, (l, h) in enumerate(sizes)])
+    if group is None:
+        group = default_group()
+    return np.concatenate(group.allgather_array(mine))
 
 
 def env_rank():
@@ -67,16 +63,32 @@ def env_rank():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def rank_context(process_group=None):
-    """Create the ``_native.Context`` of this rank, distributing the RCCL unique id through an already
-    initialised ``torch.distributed`` process group (gloo or nccl)."""
+_default_group = None
+
+
+def default_group(timeout=300.0):
+    """Process-wide ``HostGroup`` built from the launcher's environment on first use."""
+    global _default_group
+    if _default_group is None:
+        from .hostgroup import HostGroup
+        _default_group = HostGroup.from_env(timeout=timeout)
+    return _default_group
+
+
+def rank_context(group=None, device=None):
+    """Create the ``_native.Context`` of this rank: rank 0 asks RCCL for a unique id, the host group carries it to the
+    other ranks, every rank joins the communicator.  The group stays attached to the context (``ctx.host_group``):
+    ``Runner`` uses it to start every rank from the same walkers and the same sampler seed."""
     from . import _native
     rank, world, local_rank = env_rank()
+    dev = local_rank if device is None else int(device)
     if world == 1:
-        return _native.Context(n_devices=1, device_ids=[local_rank])
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    box = [_native.Context.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0, group=process_group)
-    return _native.Context(rank=rank, n_ranks=world, unique_id=box[0], device=local_rank)
+        ctx = _native.Context(n_devices=1, device_ids=[dev])
+        ctx.host_group = None
+        return ctx
+    if group is None:
+        group = default_group()
+    uid = group.bcast_bytes(_native.Context.unique_id() if rank == 0 else None, src=0)
+    ctx = _native.Context(rank=rank, n_ranks=world, unique_id=uid, device=dev)
+    ctx.host_group = group
+    return ctx

@@ -122,11 +122,130 @@ def golden_single_stars():
          **out)
 
 
+def _table_rows(results, names):
+    """(3, len(names)) float array of a reference results table: rows median / uperr / loerr."""
+    out = np.empty((3, len(names)))
+    for j, name in enumerate(names):
+        for i, row in enumerate(("median", "uperr", "loerr")):
+            x = results.loc[row][name]
+            out[i, j] = float(getattr(x, "value", x))
+    return out
+
+
+def golden_round2():
+    """Fixtures added in round 2 (the others are left untouched):
+
+    * ``chain_stats``: a fixed synthetic chain through the reference's chain post-processing --
+      ``Runner.compute_percentiles`` / ``compute_bestfit_values`` (runner.py:566-660), ``convert_to_parameters``
+      (runner.py:521-564), ``get_amplitude_and_angle`` (utils/coordinates/get_amplitude_and_angle.py:10-51, also with the
+      rotation axis near +-pi so that the wrap is exercised) and ``ConstantFit.compute_theta_vmax`` (constant.py:156-214);
+    * ``model_fit_gb_membership``: ``ModelFitGB.calculate_membership_probabilities`` (model.py:458-510) for that kind of chain;
+    * ``model_fit_bg_gaussian_{fixed,free}``: ``ModelFit`` with a fixed ``background=Gaussian`` (the pmember mixture of
+      ``Runner._calculate_lnlike``, runner.py:272-286, applied to the Lynden-Bell / Plummer profiles of model.py:93-222).
+    """
+    from mcmc_dynamics.utils.coordinates import get_amplitude_and_angle
+    ra_c, dec_c = synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG
+    cat = synthetic.make_catalog(600, config=2)
+
+    # ---- chain statistics on a ConstantFit with one fixed parameter in the middle of the list
+    cf = ConstantFit(reader(cat))
+    fix_center(cf, ra_c, dec_c)
+    names = list(cf.fitted_parameters)
+    rng = np.random.default_rng(20261004)
+    n_walkers, n_steps, n_burn = 10, 14, 3
+    centre_row = np.array([0.3, 9.5, -4.0, 0.4])                     # v_maxx < 0, v_maxy ~ 0: theta_0 scatters around +-pi
+    chain = centre_row + rng.normal(size=(n_walkers, n_steps, len(names))) * np.array([0.4, 0.6, 0.8, 0.9])
+    chain[:, :n_burn] += 25.0                                          # burn-in that must be discarded
+    pct_default = cf.compute_percentiles(chain, n_burn=n_burn)
+    pct_custom = cf.compute_percentiles(chain, n_burn=n_burn, pct=[2.5, 97.5])
+    best = cf.compute_bestfit_values(chain, n_burn=n_burn)
+    stored_after = np.array([float(getattr(cf.parameters[n].value, "value", cf.parameters[n].value)) for n in names])
+    pars = cf.convert_to_parameters(chain, n_burn=n_burn)
+    conv = np.stack([np.asarray(getattr(pars[k], "value", pars[k]), dtype=np.float64) for k in cf.parameters])
+    res, v_max, theta = get_amplitude_and_angle({k: np.asarray(getattr(v, "value", v), dtype=np.float64)
+                                                 for k, v in pars.items()}, return_samples=True)
+    res2 = cf.compute_theta_vmax(chain, n_burn=n_burn)                  # return_samples=True raises KeyError('sigma') upstream
+    # a second chain whose axis sits in the first quadrant (no wrap)
+    chain_b = np.array([0.0, 8.0, 2.0, 3.0]) + rng.normal(size=(n_walkers, n_steps, len(names))) * 0.3
+    pars_b = cf.convert_to_parameters(chain_b, n_burn=0)
+    res_b, v_max_b, theta_b = get_amplitude_and_angle({k: np.asarray(getattr(v, "value", v), dtype=np.float64)
+                                                       for k, v in pars_b.items()}, return_samples=True)
+    # theta_0 given instead of v_maxx (second branch of get_amplitude_and_angle.py:14-15)
+    alt = {"theta_0": theta_b + 0.0, "v_maxy": np.asarray(getattr(pars_b["v_maxy"], "value", pars_b["v_maxy"]), dtype=np.float64)}
+    alt["theta_0"] = np.arctan2(alt["v_maxy"], np.asarray(getattr(pars_b["v_maxx"], "value", pars_b["v_maxx"]), dtype=np.float64))
+    res_c, v_max_c, theta_c = get_amplitude_and_angle(dict(alt), return_samples=True)
+    save("chain_stats", ra=cat["ra"], dec=cat["dec"], v=cat["v"], verr=cat["verr"], ra_center=ra_c, dec_center=dec_c,
+         names=names, all_names=list(cf.parameters), chain=chain, n_burn=n_burn,
+         percentiles_default=pct_default, percentiles_custom=pct_custom, bestfit=_table_rows(best, names),
+         parameters_after_bestfit=stored_after, converted=conv,
+         amp_angle=_table_rows(res, ["v_max", "theta_0"]), v_max_samples=np.asarray(v_max), theta_samples=np.asarray(theta),
+         theta_vmax_method=_table_rows(res2, ["v_max", "theta_0"]),
+         chain_b=chain_b, amp_angle_b=_table_rows(res_b, ["v_max", "theta_0"]), v_max_samples_b=np.asarray(v_max_b),
+         theta_samples_b=np.asarray(theta_b),
+         amp_angle_c=_table_rows(res_c, ["v_max", "theta_0"]), v_max_samples_c=np.asarray(v_max_c),
+         theta_samples_c=np.asarray(theta_c))
+
+    # ---- ModelFitGB.calculate_membership_probabilities
+    catb = synthetic.make_catalog(900, config=3, background=True)
+    truth_b = dict(catb["truth"], a=30.0, r_peak=60.0)
+    for free in (False, True):
+        mg = ModelFitGB(reader(catb, extra=("density",)))
+        if free:
+            mg.parameters["ra_center"].set(value=ra_c * u.deg)
+            mg.parameters["dec_center"].set(value=dec_c * u.deg)
+        else:
+            fix_center(mg, ra_c, dec_c)
+        names_g = list(mg.fitted_parameters)
+        mid = np.array([truth_b[n] for n in names_g], dtype=np.float64)
+        scale = np.array([(0.05 / 60.0) if n in ("ra_center", "dec_center") else (0.5 if truth_b[n] == 0.0 else 0.05 * abs(truth_b[n]))
+                          for n in names_g])
+        chain_g = mid + rng.normal(size=(8, 9, len(names_g))) * scale
+        chain_g[..., names_g.index("f_back")] = np.clip(chain_g[..., names_g.index("f_back")], 0.01, 0.99)
+        member = mg.calculate_membership_probabilities(chain_g, n_burn=2)
+        best_g = mg.compute_bestfit_values(chain_g, n_burn=2)
+        save("model_fit_gb_membership" + ("_free" if free else "_fixed"),
+             ra=catb["ra"], dec=catb["dec"], v=catb["v"], verr=catb["verr"], density=catb["density"],
+             ra_center=ra_c, dec_center=dec_c, names=names_g, chain=chain_g, n_burn=2,
+             median=_table_rows(best_g, names_g)[0],
+             membership=np.asarray(getattr(member, "value", member), dtype=np.float64))
+
+    # ---- ModelFit + fixed Gaussian background
+    bg = Gaussian(mean=20.0 * KMS, sigma=40.0 * KMS)
+    for free in (False, True):
+        mf = ModelFit(reader(catb, extra=("pmember",)), background=bg)
+        if free:
+            mf.parameters["ra_center"].set(value=ra_c * u.deg)
+            mf.parameters["dec_center"].set(value=dec_c * u.deg)
+        else:
+            fix_center(mf, ra_c, dec_c)
+        names_m = list(mf.fitted_parameters)
+        rng_m = np.random.default_rng(31)
+        pos = np.empty((16, len(names_m)))
+        for j, nme in enumerate(names_m):
+            t = truth_b[nme]
+            g = rng_m.normal(size=16)
+            pos[:, j] = t + (0.05 / 60.0) * g if nme in ("ra_center", "dec_center") else (0.5 * g if t == 0.0 else t * (1.0 + 0.05 * g))
+        pos[-1, names_m.index("r_peak")] = -5.0             # rejected by the prior
+        pos[-2, names_m.index("sigma_max")] = 0.0           # inclusive bound
+        save("model_fit_bg_gaussian" + ("_free" if free else "_fixed"),
+             ra=catb["ra"], dec=catb["dec"], v=catb["v"], verr=catb["verr"], pmember=catb["pmember"],
+             bg_mean=20.0, bg_sigma=40.0, lnlike_background=np.asarray(mf.lnlike_background, dtype=np.float64),
+             ra_center=ra_c, dec_center=dec_c, names=names_m, values=pos, lnprob=lnprobs(mf, pos), lnprior=lnpriors(mf, pos))
+    with open(os.path.join(OUT, "PROVENANCE.txt"), "a") as f:
+        import astropy
+        f.write("round 2 fixtures (chain_stats, model_fit_gb_membership_*, model_fit_bg_gaussian_*): "
+                "oracle/make_golden.py round2, python {0}, numpy {1}, astropy {2}\n".format(
+                    sys.version.split()[0], np.__version__, astropy.__version__))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["round2"]:               # the fixtures added in round 2 only
+        return golden_round2()
     if sys.argv[1:] == ["single_stars"]:          # regenerate one fixture without rewriting the others
         return golden_single_stars()
     golden_single_stars()
+    golden_round2()
     ra_c, dec_c = synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG
 
     # ---------------------------------------------------------------- ConstantFit, fixed centre

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <vector>
 
+#include "mcd_chunks.h"
 #include "mcd_guard.h"
 #include "mcd_math.h"
 
@@ -141,4 +142,100 @@ extern "C" int emul_kde(int64_t m, const double* comp, int64_t n, const double* 
         out[i] = -d2 * h + std::log(total / std::sqrt(2.0 * 3.14159265358979323846 * norm)) - std::log((double)m);
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Work decomposition (csrc/mcd_chunks.h): the chunk table the library builds for one shard, and a complete sharded
+// evaluation carried out the way the library does it -- per shard: plan_chunks, one partial sum per (chunk, walker)
+// with the kernel family the chunk's flag selects, the walker-independent background sum of the shard's stars, then
+// the sum over shards (what the all-reduce delivers).
+extern "C" int64_t emul_plan_chunks(int64_t n_psets, const int64_t* bin_offsets, int64_t star_begin, int64_t n,
+                                    int64_t n_walkers, int64_t target_waves, int tail_split, int64_t n_exc,
+                                    const int64_t* exc, int64_t cap, int64_t* begin, int32_t* count, int32_t* pset,
+                                    uint8_t* general, int64_t* offsets, int64_t* info) {
+    const std::vector<int64_t> offs(bin_offsets, bin_offsets + n_psets + 1);
+    const std::vector<int64_t> ex(exc, exc + n_exc);
+    const ChunkPlan plan = plan_chunks(offs, star_begin, n, n_walkers, target_waves, tail_split, ex);
+    const int64_t nc = (int64_t)plan.chunks.size();
+    if (nc > cap) return -nc;
+    for (int64_t i = 0; i < nc; ++i) {
+        begin[i] = plan.chunks[i].begin; count[i] = plan.chunks[i].count; pset[i] = plan.chunks[i].pset;
+        general[i] = plan.general.empty() ? 0 : plan.general[i];
+    }
+    for (int64_t p = 0; p <= n_psets; ++p) offsets[p] = plan.offsets[p];
+    info[0] = plan.max_chunks_per_pset; info[1] = plan.len; info[2] = plan.uniform_len;
+    info[3] = plan.general.empty() ? 0 : 1; info[4] = main_grid(nc, n_walkers);
+    return nc;
+}
+
+extern "C" void emul_shard_range(int64_t n_stars, int i, int n_shards, int64_t* out) {
+    const ShardRange r = shard_range(n_stars, i, n_shards);
+    out[0] = r.begin; out[1] = r.n;
+}
+
+extern "C" void emul_pset_background_sums(const double* lnbg, int64_t n_psets, const int64_t* bin_offsets,
+                                          int64_t star_begin, int64_t n, double* out) {
+    const std::vector<int64_t> offs(bin_offsets, bin_offsets + n_psets + 1);
+    const std::vector<double> sums = pset_background_sums(lnbg, offs, star_begin, n);
+    for (int64_t p = 0; p < n_psets; ++p) out[p] = sums[p];
+}
+
+template <int MODEL, bool FREE>
+static void sharded(int level, int64_t n, const double* recs, int64_t n_psets, const int64_t* bin_offsets,
+                    const double* lnbg, const std::vector<int64_t>& exc, int64_t W, const double* wpar, int n_shards,
+                    int64_t target_waves, int tail_split, double* out, int64_t* n_general) {
+    constexpr int ND = record_doubles(MODEL, FREE);
+    constexpr int BG = bg_kind(MODEL);
+    const std::vector<int64_t> offs(bin_offsets, bin_offsets + n_psets + 1);
+    const double* tab = exp_table_is_sqrt2_scaled(MODEL) ? kExpTabSqrt2Host : kExpTabHost;
+    for (int64_t i = 0; i < n_psets * W; ++i) out[i] = 0.0;
+    *n_general = 0;
+    for (int sidx = 0; sidx < n_shards; ++sidx) {
+        const ShardRange sr = shard_range(n, sidx, n_shards);
+        const ChunkPlan plan = plan_chunks(offs, sr.begin, sr.n, W, target_waves, tail_split, exc);
+        const double* shard_recs = recs + sr.begin * ND;            // what this device holds
+        std::vector<double> acc(n_psets * W, 0.0);
+        for (size_t c = 0; c < plan.chunks.size(); ++c) {
+            const Chunk& ch = plan.chunks[c];
+            const bool general = !plan.general.empty() && plan.general[c];
+            if (general) ++*n_general;
+            for (int64_t w = 0; w < W; ++w) {
+                WalkerConsts<double> wc;
+                wc.load(wpar + ((int64_t)ch.pset * W + w) * KD);
+                bool den;
+                double r;
+                if (level == 0) r = chunk_loglike<MODEL, FREE, double, double, 0>(shard_recs + ch.begin * ND, ch.count, wc, den, tab);
+                else if (level == 1 || general || BG == BG_NONE) r = chunk_loglike<MODEL, FREE, double, double, 1>(shard_recs + ch.begin * ND, ch.count, wc, den, tab);
+                else r = chunk_loglike<MODEL, FREE, double, double, (BG == BG_NONE ? 1 : 2)>(shard_recs + ch.begin * ND, ch.count, wc, den, tab);
+                acc[(int64_t)ch.pset * W + w] += r;
+            }
+        }
+        if (level && lnbg && (BG == BG_FIXED || BG == BG_FIXED_DENSITY)) {
+            const std::vector<double> sums = pset_background_sums(lnbg, offs, sr.begin, sr.n);
+            for (int64_t p = 0; p < n_psets; ++p)
+                for (int64_t w = 0; w < W; ++w) acc[p * W + w] += sums[p];
+        }
+        for (int64_t i = 0; i < n_psets * W; ++i) out[i] += acc[i];          // the all-reduce
+    }
+}
+
+extern "C" int emul_sharded_loglike(int model, int free_centre, int level, int64_t n, const double* recs,
+                                    int64_t n_psets, const int64_t* bin_offsets, const double* lnbg, int64_t n_exc,
+                                    const int64_t* exc, int64_t W, const double* wpar, int n_shards,
+                                    int64_t target_waves, int tail_split, double* out, int64_t* n_general) {
+    const std::vector<int64_t> ex(exc, exc + n_exc);
+#define CASE(M, F, X) if (X && model == M && (free_centre != 0) == F) { sharded<M, F>(level, n, recs, n_psets, bin_offsets, lnbg, ex, W, wpar, n_shards, target_waves, tail_split, out, n_general); return 0; }
+    FOR_ALL(0) FOR_ALL(1) FOR_ALL(2) FOR_ALL(3) FOR_ALL(4) FOR_ALL(5)
+#undef CASE
+    return -1;
+}
+
+// narrow_exception star list of a catalogue (mcd_guard.h: compute_stats), ascending global indices
+extern "C" int64_t emul_narrow_exceptions(int model, int64_t n, const double* v, const double* verr, const double* lnbg,
+                                          const double* pmember, const double* density, int64_t cap, int64_t* out) {
+    const CatalogStats st = compute_stats(n, v, verr, lnbg, pmember, density, bg_kind(model));
+    if (!st.narrow_possible) return -1;
+    const int64_t m = (int64_t)st.narrow_exceptions.size();
+    for (int64_t i = 0; i < m && i < cap; ++i) out[i] = st.narrow_exceptions[i];
+    return m;
 }

@@ -23,7 +23,7 @@ def lib():
     global _lib
     if _lib is None:
         deps = [SRC, os.path.join(INC, "mcd_math.h"), os.path.join(INC, "mcd_guard.h"),
-                os.path.join(INC, "mcd_exp_table.h")]
+                os.path.join(INC, "mcd_exp_table.h"), os.path.join(INC, "mcd_chunks.h")]
         if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", INC, SRC,
                             "-o", OUT], check=True)
@@ -61,13 +61,13 @@ def pack_records(cat, model, centre):
     if bg == 1:
         b, p = cat["lnlike_bg"], cat["pmember"]
         with np.errstate(divide="ignore", invalid="ignore"):
-            cols += [b, p, 1.0 - p, np.fmax(np.log(p) - (b + HALF_LN_2PI), -1.0e5)]
+            cols += [b, p, 1.0 - p, np.fmax(np.log(p) - (b + HALF_LN_2PI), -2000.0)]
     elif bg == 2:
         cols += [cat["density"], np.zeros(n)]
     elif bg == 3:
         b = cat["lnlike_bg"]
         with np.errstate(divide="ignore", invalid="ignore"):
-            cols += [b, np.fmax(np.log(cat["density"]) - (b + HALF_LN_2PI), -1.0e5), cat["density"], np.zeros(n)]
+            cols += [b, np.fmax(np.log(cat["density"]) - (b + HALF_LN_2PI), -2000.0), cat["density"], np.zeros(n)]
     return np.ascontiguousarray(np.stack(cols, axis=1), dtype=np.float64)
 
 
@@ -142,3 +142,90 @@ def fast_level(cat, params, model, centre, f32=False):
     ptr = [c.ctypes.data if c is not None else None for c in cols]
     return int(lib().emul_fast_guard(model, int(centre is None), int(f32), len(cat["v"]), *ptr, params.shape[1],
                                      params.ctypes.data, params.shape[0]))
+
+
+# ---- work decomposition (csrc/mcd_chunks.h) ---------------------------------------------------------------------
+def plan_chunks(bin_offsets, star_begin, n, n_walkers, target_waves=12288, tail_split=1, exceptions=()):
+    """The chunk table the library builds for the shard [star_begin, star_begin + n): dict of arrays + scalars."""
+    L = lib()
+    offs = np.ascontiguousarray(bin_offsets, dtype=np.int64)
+    exc = np.ascontiguousarray(exceptions, dtype=np.int64)
+    cap = int(n) // 8 + 8 * len(offs) + 64
+    begin, count, pset = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
+    general, offsets, info = np.empty(cap, np.uint8), np.empty(len(offs), np.int64), np.empty(5, np.int64)
+    L.emul_plan_chunks.restype = ctypes.c_int64
+    L.emul_plan_chunks.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                   ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + \
+        [ctypes.c_void_p] * 6
+    nc = L.emul_plan_chunks(len(offs) - 1, offs.ctypes.data, int(star_begin), int(n), int(n_walkers), int(target_waves),
+                            int(tail_split), len(exc), exc.ctypes.data, cap, begin.ctypes.data, count.ctypes.data,
+                            pset.ctypes.data, general.ctypes.data, offsets.ctypes.data, info.ctypes.data)
+    assert nc >= 0, "chunk capacity"
+    return {"begin": begin[:nc], "count": count[:nc], "pset": pset[:nc], "general": general[:nc], "offsets": offsets,
+            "max_chunks_per_pset": int(info[0]), "len": int(info[1]), "uniform_len": int(info[2]),
+            "has_general": bool(info[3]), "grid": int(info[4])}
+
+
+def shard_range(n_stars, i, n_shards):
+    out = np.empty(2, np.int64)
+    lib().emul_shard_range.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib().emul_shard_range(int(n_stars), int(i), int(n_shards), out.ctypes.data)
+    return int(out[0]), int(out[1])
+
+
+def pset_background_sums(lnbg, bin_offsets, star_begin, n):
+    offs = np.ascontiguousarray(bin_offsets, dtype=np.int64)
+    lnbg = np.ascontiguousarray(lnbg, dtype=np.float64)
+    out = np.empty(len(offs) - 1)
+    lib().emul_pset_background_sums.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                                ctypes.c_int64, ctypes.c_void_p]
+    lib().emul_pset_background_sums(lnbg.ctypes.data, len(offs) - 1, offs.ctypes.data, int(star_begin), int(n),
+                                    out.ctypes.data)
+    return out
+
+
+def narrow_exceptions(cat, model):
+    """Ascending star indices that rule out the narrow-range variant for their chunk; None when the catalogue has too
+    many of them (the library then uses the general fast form throughout)."""
+    cols = [np.ascontiguousarray(cat[k], dtype=np.float64) if k in cat else None
+            for k in ("v", "verr", "lnlike_bg", "pmember", "density")]
+    n = len(cat["v"])
+    out = np.empty(n, np.int64)
+    lib().emul_narrow_exceptions.restype = ctypes.c_int64
+    lib().emul_narrow_exceptions.argtypes = [ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
+    m = lib().emul_narrow_exceptions(model, n, *[c.ctypes.data if c is not None else None for c in cols], n, out.ctypes.data)
+    return None if m < 0 else out[:m].copy()
+
+
+def sharded_loglike(cat, params, model, centre, level, n_shards, bin_offsets=None, target_waves=12288, tail_split=1,
+                    n_walkers=None):
+    """A complete evaluation the way the library carries it out over `n_shards` devices / ranks (chunk tables per shard,
+    per-chunk kernel family, per-shard background sums, sum over shards).  params: (W, K) or (B, W, K) in C-ABI order.
+    Returns (out, number of chunks that took the general form)."""
+    rec = pack_records(cat, model, centre)
+    n = rec.shape[0]
+    offs = np.ascontiguousarray([0, n] if bin_offsets is None else bin_offsets, dtype=np.int64)
+    n_psets = len(offs) - 1
+    p = np.asarray(params, dtype=np.float64)
+    if p.ndim == 2:
+        p = p[None]
+    assert p.shape[0] == n_psets
+    W = p.shape[1]
+    wp = np.ascontiguousarray(np.stack([pack_walkers(p[b], model, centre is None) for b in range(n_psets)]))
+    exc = narrow_exceptions(cat, model) if level == 2 else np.empty(0, np.int64)
+    if exc is None:
+        level, exc = 1, np.empty(0, np.int64)
+    lnbg = np.ascontiguousarray(cat["lnlike_bg"], dtype=np.float64) if "lnlike_bg" in cat and BG_OF[model] in (1, 3) else None
+    out = np.empty((n_psets, W))
+    n_general = ctypes.c_int64(0)
+    L = lib()
+    L.emul_sharded_loglike.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.emul_sharded_loglike(model, int(centre is None), int(level), n, rec.ctypes.data, n_psets, offs.ctypes.data,
+                                lnbg.ctypes.data if lnbg is not None else None, len(exc), exc.ctypes.data, W,
+                                wp.ctypes.data, int(n_shards), int(target_waves), int(tail_split), out.ctypes.data,
+                                ctypes.byref(n_general))
+    assert rc == 0
+    return (out[0] if n_psets == 1 else out), n_general.value

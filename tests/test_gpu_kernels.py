@@ -309,9 +309,11 @@ def test_rank_mode_context_single_rank(native):
     assert np.array_equal(a, b)
 
 
-def test_rccl_call_path_on_one_rank(native):
-    """MCD_FORCE_RCCL=1: unique id -> ncclCommInitRank(1 rank) -> ncclAllReduce(sum, f64) on the catalogue's
-    stream.  Exercises librccl loading and the collective call site on a single GPU; sums are unchanged."""
+@pytest.mark.parametrize("kind", ["rank", "single_process"])
+def test_rccl_call_path_on_one_rank(native, kind):
+    """MCD_FORCE_RCCL=1, both context kinds: unique id -> ncclCommInitRank(1 rank) (one process per GPU), and
+    ncclCommInitAll(1 device) + ncclGroupStart/End (one process, several GPUs) -> ncclAllReduce(sum, f64) on the
+    catalogue's stream.  Exercises librccl loading and the collective call site on a single GPU; sums are unchanged."""
     import os
     from mcmc_dynamics_amd import synthetic
     c, centre = _synthetic(5000, 4)
@@ -320,11 +322,17 @@ def test_rccl_call_path_on_one_rank(native):
                          centre=centre).loglike(pos)
     os.environ["MCD_FORCE_RCCL"] = "1"
     try:
-        uid = native.Context.unique_id()
-        assert len(uid) == native.UNIQUE_ID_BYTES and any(uid)
-        ctx1 = native.Context(rank=0, n_ranks=1, unique_id=uid, device=0)
+        if kind == "rank":
+            uid = native.Context.unique_id()
+            assert len(uid) == native.UNIQUE_ID_BYTES and any(uid)
+            ctx1 = native.Context(rank=0, n_ranks=1, unique_id=uid, device=0)
+        else:
+            ctx1 = native.Context(n_devices=1)
     finally:
         del os.environ["MCD_FORCE_RCCL"]
+    info = ctx1.comm_info()                                   # what RCCL itself says about the communicator
+    assert info["size"] == 1 and info["rank"] == 0 and info["rccl_version"] > 20000, info
+    assert native.default_context().comm_info()["size"] == 0  # the plain single-GPU context never loads RCCL
     cat = native.Catalog(ctx1, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
     for _ in range(3):
         assert np.array_equal(cat.loglike(pos), ref)
