@@ -10,14 +10,25 @@ all-reduce of 256 doubles when N > 1]).  Default workload = the configuration BA
 is quoted on (C3 of SURVEY.md section 8): 1e6 synthetic stars per GPU x 256 walkers, rotation +
 dispersion + fixed single-Gaussian background mixture, float64.  Star records and the walker table are
 resident in HBM before the timed region.  For N > 1 every rank holds its own 1e6-star shard (weak
-scaling) and the per-walker partial sums are all-reduced over xGMI.
+scaling) and the per-walker partial sums are all-reduced over xGMI.  Every run (any N, default
+workload) also times the north-star strong-scaling case, C4: ONE 1e7-star catalogue sharded over the N
+ranks (``c4_strong`` in the JSON line), so that a sweep over N yields the strong-scaling curve.
+
+No PyTorch anywhere: the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) is read
+directly, rank 0's RCCL unique id, barriers and max-over-ranks travel over ``mcmc_dynamics_amd.hostgroup``
+(plain TCP), so the process runs on the ROCm libraries ``libmcd_hip.so`` was built against.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+If the collective cannot be set up or its first all-reduce hangs, rank 0 prints a line with
+``"degraded": true`` and ``"value": null`` and EVERY rank exits with status 3: no number is reported
+from a process that sits beside a blocked GPU context.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,14 +38,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip table)
-# f64 VALU issue model (the resource that actually binds these kernels):
-#   slots per term of the fast-path inner loops from the gfx950 ISA (tools/isa_mix.py; bgfixed / bggauss = the narrow-range variants
-#   the guard selects for the bench catalogue), one slot = one f64 wave-instruction
-#   per SIMD = 2.33 ns on the fully occupied chip (tools/valu_rate_probe.hip).
-VALU_SLOTS_PER_TERM = {"const": 8.56, "bgfixed": 26.65, "bggauss": 49.55, "profile": 27.91}
-VALU_SLOT_NS = 2.33
-COLLECTIVE_TIMEOUT_S = 180
+# f64 VALU issue peak, the roof that binds these kernels: 256 CUs x 4 SIMDs, one wave64 f64
+# vector instruction per 4 cycles per SIMD, 2.4 GHz max clock (MI355X_MICROARCH.md: chip table, wave scheduling)
 N_SIMD = 256 * 4
+MAX_CLOCK_HZ = 2.4e9
+VALU_F64_PEAK = N_SIMD * MAX_CLOCK_HZ / 4.0          # 6.144e11 wave-instructions / s
+COLLECTIVE_TIMEOUT_S = 180
+EXIT_COLLECTIVE = 3
+ISA_MIX = os.path.join(ROOT, "mcmc_dynamics_amd", "csrc", "isa_mix.json")
 
 WORKLOADS = {
     # name: (description, stars per GPU, walkers, model, algorithmic bytes per term, config number)
@@ -52,6 +63,7 @@ WORKLOADS = {
     "c5": ("C5: radial-binned dispersion profile (make_radial_bins nstars=1000, dlogr=0.05), 1e6 synthetic stars x 512 "
            "walkers per bin, rotation+dispersion, one segmented launch for all bins", 1000000, 512, "const", 32, 5),
 }
+NAMES4 = ["v_sys", "sigma_max", "v_maxx", "v_maxy"]
 
 
 def parse_args():
@@ -69,10 +81,12 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores pool baseline")
     ap.add_argument("--no-mcmc", action="store_true", help="skip the sampler-driven end-to-end figure (profiling runs)")
+    ap.add_argument("--no-c4-strong", action="store_true", help="skip the 1e7-star strong-scaling sub-record")
+    ap.add_argument("--c4-stars", type=int, default=10000000, help="total stars of the strong-scaling sub-record")
     return ap.parse_args()
 
 
-def build_catalog(native, ctx, synthetic, oracle, cat, model, precision="f64", bin_offsets=None):
+def build_catalog(native, ctx, synthetic, cat, model, precision="f64", bin_offsets=None):
     centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
     if model == "const":
         return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST, centre=centre,
@@ -82,16 +96,16 @@ def build_catalog(native, ctx, synthetic, oracle, cat, model, precision="f64", b
         from mcmc_dynamics_amd.background import Gaussian
         lnbg = Gaussian(synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])(cat["v"], cat["verr"])
         return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST_BGFIXED,
-                              centre=centre, lnlike_bg=lnbg, pmember=cat["pmember"])
+                              centre=centre, lnlike_bg=lnbg, pmember=cat["pmember"], precision=precision)
     if model == "profile":
-        return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_PROFILE, centre=centre)
+        return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_PROFILE, centre=centre,
+                              precision=precision)
     return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST_BGGAUSS,
-                          centre=centre, density=cat["density"])
+                          centre=centre, density=cat["density"], precision=precision)
 
 
-def cpu_baseline(cat, pos, model, budget_s):
-    """The oracle's faithful op-for-op NumPy restatement (one walker per call, as the reference's
-    ``Runner.lnprob``), timed on one host core over a bounded number of walkers."""
+# ---------------------------------------------------------------------------------------------- CPU baseline (oracle)
+def _cpu_one(cat, model):
     from oracle import lnprob_numpy as oracle
     from mcmc_dynamics_amd import synthetic
     centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
@@ -107,7 +121,13 @@ def cpu_baseline(cat, pos, model, budget_s):
             return oracle.faithful_model_lnlike(cat, row[0], row[1], row[2], row[3], row[4], row[5], centre[0], centre[1])
         return oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
                                                lnlike_background=lnbg, pmember=cat.get("pmember") if lnbg is not None else None)
+    return one
 
+
+def cpu_baseline(cat, pos, model, budget_s):
+    """The oracle's faithful op-for-op NumPy restatement (one walker per call, as the reference's
+    ``Runner.lnprob``), timed on one host core over a bounded number of walkers."""
+    one = _cpu_one(cat, model)
     one(pos[0])                                   # warm the allocator / caches
     n, t0 = 0, time.perf_counter()
     vals = []
@@ -140,21 +160,7 @@ def cpu_baseline_all_cores(cat, pos, model, per_walker_s, budget_s):
     """The same NumPy port on every host core this process may use.  Must run BEFORE the HIP runtime is
     initialised (plain fork, no exec); bounded by a hard timeout so that it can never stall the bench."""
     import multiprocessing as mp
-    from oracle import lnprob_numpy as oracle
-    from mcmc_dynamics_amd import synthetic
-    centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
-    lnbg = None
-    if model == "bgfixed":
-        lnbg = oracle.gaussian_background(cat["v"], cat["verr"], synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])
-
-    def one(row):
-        if model == "bggauss":
-            return oracle.faithful_constant_gb_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
-                                                      row[4], row[5], row[6])
-        return oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], centre[0], centre[1],
-                                               lnlike_background=lnbg, pmember=cat.get("pmember") if lnbg is not None else None)
-
-    _POOL_STATE["one"] = one
+    _POOL_STATE["one"] = _cpu_one(cat, model)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     per_worker = max(1, min(len(pos) // cores, int(budget_s / max(per_walker_s, 1e-3))))
@@ -174,6 +180,208 @@ def cpu_baseline_all_cores(cat, pos, model, per_walker_s, budget_s):
                       "(slowest worker busy {4:.1f} s)".format(n, len(cat["v"]), cores, wall, max(busy))}
 
 
+# ---------------------------------------------------------------------------------------------- helpers
+def mapped_libraries():
+    """Which HIP runtime / RCCL / kernel library this process actually mapped (from /proc/self/maps)."""
+    found = {}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split()[-1]
+                base = os.path.basename(path)
+                for key in ("libamdhip64", "librccl", "libmcd_hip", "libhsa-runtime64"):
+                    if base.startswith(key):
+                        found[key] = path
+    except OSError:
+        pass
+    return found
+
+
+def isa_counts(model):
+    """VALU wave-instructions per star-walker term of the model's hot loop, as emitted by tools/isa_mix.py at build time
+    (mcmc_dynamics_amd/csrc/isa_mix.json; regenerated here when it does not belong to the sources in the tree)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import isa_mix
+        want = isa_mix.source_hash()
+        data = None
+        if os.path.exists(ISA_MIX):
+            with open(ISA_MIX) as f:
+                data = json.load(f)
+        if data is None or data.get("source_sha16") != want:
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), "--json", ISA_MIX],
+                                 capture_output=True, timeout=600)
+            if res.returncode != 0:
+                return None, "tools/isa_mix.py failed: " + res.stderr.decode()[-200:]
+            with open(ISA_MIX) as f:
+                data = json.load(f)
+        row = data["kernels"].get(model)
+        if row is None:
+            return None, "no entry for " + model
+        return row, "mcmc_dynamics_amd/csrc/isa_mix.json (tools/isa_mix.py at build, sources sha16 {0})".format(data["source_sha16"])
+    except Exception as exc:                               # the roofline block degrades to null, the bench line survives
+        return None, repr(exc)
+
+
+def smi_snapshot():
+    try:
+        res = subprocess.run(["rocm-smi", "--showuse", "--showmemuse", "--showpids", "--json"], capture_output=True, timeout=3)
+        return res.stdout.decode()[-1500:]
+    except Exception as exc:
+        return repr(exc)
+
+
+def fail_collective(rank, world, args, stage, reason, group=None):
+    """The collective could not be set up or did not complete: rank 0 prints a marked line with no value; every rank
+    leaves with a non-zero status WITHOUT running destructors (the GPU context may be blocked for good).  The other ranks
+    linger a few seconds so that the launcher does not tear rank 0 down before its line is out."""
+    sys.stderr.write("bench.py rank {0}: collective failure at {1}: {2}\n".format(rank, stage, reason))
+    sys.stderr.flush()
+    if rank == 0:
+        line = {"metric": "star-walker log-L terms/sec", "value": None, "unit": "terms/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "degraded": True,
+                "config": {"workload": WORKLOADS[args.workload][0]},
+                "failure": {"stage": stage, "reason": reason, "rank_reporting": rank, "libraries": mapped_libraries(),
+                            "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "HIP_VISIBLE_DEVICES",
+                                                                   "ROCR_VISIBLE_DEVICES", "MASTER_ADDR", "MASTER_PORT")}},
+                "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+        sys.stderr.write("rocm-smi at failure: {0}\n".format(smi_snapshot()))    # for root-causing; after the line is out
+        sys.stderr.flush()
+    else:
+        time.sleep(4.0)
+    os._exit(EXIT_COLLECTIVE)
+
+
+def first_collective(gpu_cat, group, rank, world, args):
+    """Watchdog for the first collective (RCCL builds its xGMI rings lazily inside it): the enqueue runs in a helper
+    thread; if any rank's all-reduce has not completed after COLLECTIVE_TIMEOUT_S the run ends with the marked line and a
+    non-zero exit status on every rank."""
+    done = threading.Event()
+    error = []
+
+    def step():
+        try:
+            gpu_cat.enqueue()
+            gpu_cat.sync()
+            done.set()
+        except Exception as exc:
+            error.append(repr(exc))
+    worker = threading.Thread(target=step, daemon=True)
+    worker.start()
+    worker.join(COLLECTIVE_TIMEOUT_S)
+    ok = 1 if done.is_set() else 0
+    try:
+        all_ok = int(group.allreduce(np.array([ok], dtype=np.int64), op="min")[0])
+    except Exception as exc:
+        fail_collective(rank, world, args, "first all-reduce", "host group failed while agreeing on the outcome: {0!r}".format(exc))
+    if not all_ok:
+        why = error[0] if error else ("no completion within {0} s".format(COLLECTIVE_TIMEOUT_S) if not ok else "another rank failed")
+        fail_collective(rank, world, args, "first all-reduce", why)
+
+
+def timed_steps(gpu_cat, group, steps, warmup, ramp_seconds, stride):
+    """W untimed warm-up steps (after an untimed clock ramp), then exactly K pipelined steps between two barriers +
+    device syncs; returns the max-over-ranks wall time and this rank's sampled kernel time."""
+    def barrier():
+        gpu_cat.sync()
+        if group is not None:
+            group.barrier()
+
+    gpu_cat.set_option("timing", 2)
+    gpu_cat.set_option("timing_reserve", min(65536, max(steps, warmup) + 32))   # no hipEventCreate inside the timed region
+    # first launches after idle (no ramp): what a short job sees before the clocks have settled
+    gpu_cat.set_option("timing_stride", 1)
+    gpu_cat.enqueue()
+    gpu_cat.sync()
+    gpu_cat.timing_collect()
+    for _ in range(20):
+        gpu_cat.enqueue()
+    cold_ms, cold_n = gpu_cat.timing_collect()
+    gpu_cat.set_option("timing_stride", stride)
+    # Clock ramp (untimed, before the W warm-up steps): the GPU needs some 100 ms of load to reach its sustained clocks.
+    # Every rank runs the same number of launches (the all-reduce is collective).
+    ramp_steps = 0
+    if ramp_seconds > 0:
+        t_r = time.perf_counter()
+        for _ in range(8):
+            gpu_cat.enqueue()
+        gpu_cat.sync()
+        per_step = max((time.perf_counter() - t_r) / 8, 1e-6)
+        ramp_steps = int(min(20000, ramp_seconds / per_step))
+        if group is not None:
+            ramp_steps = int(group.allreduce(np.array([ramp_steps], dtype=np.int64), op="max")[0])
+        for _ in range(ramp_steps):
+            gpu_cat.enqueue()
+    for _ in range(warmup):
+        gpu_cat.enqueue()
+    barrier()
+    gpu_cat.timing_collect()                         # drop ramp and warm-up launches
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gpu_cat.enqueue()
+    gpu_cat.sync()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        group.barrier()
+        elapsed = float(group.allreduce(np.array([elapsed]), op="max")[0])
+    kernel_ms_total, n_launch = gpu_cat.timing_collect()
+    return {"elapsed": elapsed, "kernel_s": kernel_ms_total * 1e-3 / max(1, n_launch), "kernel_samples": int(n_launch),
+            "ramp_steps": ramp_steps, "cold_kernel_us": cold_ms * 1e3 / max(1, cold_n)}
+
+
+def blocking_calls(gpu_cat, pos, n_calls):
+    """SURVEY 8(d) timing protocol: wall time of the blocking C-ABI call (params H2D, kernels, reduce, [all-reduce on the
+    critical path], results D2H), median of >= 20 calls after 3 warm-ups."""
+    gpu_cat.set_option("timing", 0)
+    for _ in range(3):
+        gpu_cat.loglike(pos)
+    times = []
+    for _ in range(n_calls):
+        t = time.perf_counter()
+        gpu_cat.loglike(pos)
+        times.append(time.perf_counter() - t)
+    return float(np.median(times)), float(np.mean(times))
+
+
+def c4_strong(native, synthetic, ctx, group, rank, world, args):
+    """North-star strong scaling: ONE 1e7-star catalogue (block-seeded, identical for every N) sharded over the ranks,
+    rotation+dispersion, 256 walkers, one all-reduce of 256 doubles per step."""
+    from mcmc_dynamics_amd import distributed
+    n_total = int(args.c4_stars)
+    lo, hi = distributed.shard_bounds(n_total, rank, world)
+    cat = synthetic.make_catalog_range(n_total, lo, hi, config=4)
+    pos = synthetic.make_walkers(256, NAMES4, cat["truth"], config=4)
+    gpu_cat = build_catalog(native, ctx, synthetic, cat, "const")
+    gpu_cat.upload_params(pos)
+    stride = 8 if args.steps >= 64 else 4
+    t = timed_steps(gpu_cat, group, args.steps, args.warmup, min(args.clock_ramp_seconds, 0.2), stride)
+    result = gpu_cat.fetch()
+    med, mean = blocking_calls(gpu_cat, pos, 20)
+    if group is not None:
+        med = float(group.allreduce(np.array([med]), op="max")[0])
+        kernel_us = [float(x[0]) for x in group.allgather_array(np.array([t["kernel_s"] * 1e6]))]
+        identical = bool(group.same_everywhere(result))
+    else:
+        kernel_us, identical = [t["kernel_s"] * 1e6], True
+    terms = float(n_total) * 256
+    out = {"workload": "C4: one {0:.0e}-star synthetic catalogue sharded over {1} rank(s), rotation+dispersion, 256 walkers, "
+                       "fixed centre".format(n_total, world), "scaling": "strong", "stars_total": n_total,
+           "stars_per_gpu": hi - lo, "walkers": 256, "likelihood": "const", "steps": args.steps, "warmup": args.warmup,
+           "terms_per_s": terms * args.steps / t["elapsed"], "ms_per_step": t["elapsed"] / args.steps * 1e3,
+           "kernel_us_per_rank": kernel_us, "kernel_us_sampled_launches": t["kernel_samples"],
+           "allreduce": ("none (1 rank)" if world == 1 else
+                         "pipelined steps: ncclAllReduce(sum, f64, 256) on the communication stream behind an event, "
+                         "overlapping the next step's kernels (off the critical path); blocking call: on the compute stream "
+                         "(on the critical path)"),
+           "blocking_call_us_median": med * 1e6, "blocking_call_terms_per_s": terms / med,
+           "results_identical_on_all_ranks": identical,
+           "lnlike_first_walkers": [float(x) for x in result[:2]]}
+    gpu_cat.close()
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -189,6 +397,7 @@ def main():
         n_stars = args.stars
     if args.walkers is not None:
         n_walkers = args.walkers
+    names = NAMES4 + (["v_back", "sigma_back", "f_back"] if model == "bggauss" else [])
 
     # Extra CPU figure (all host cores) -- forked workers, so it runs before anything initialises the HIP runtime.
     all_cores = None
@@ -197,8 +406,7 @@ def main():
         try:
             cat0 = synthetic.make_catalog(n_stars, config=config, seed=synthetic.CATALOG_SEED_BASE + config,
                                           background=(model != "const"))
-            names0 = ["v_sys", "sigma_max", "v_maxx", "v_maxy"] + (["v_back", "sigma_back", "f_back"] if model == "bggauss" else [])
-            pos0 = synthetic.make_walkers(n_walkers, names0, cat0["truth"], config=config)
+            pos0 = synthetic.make_walkers(n_walkers, names, cat0["truth"], config=config)
             probe, _ = cpu_baseline(cat0, pos0[:2], model, 1.0)
             all_cores = cpu_baseline_all_cores(cat0, pos0, model, n_stars / probe["value"], min(args.cpu_seconds, 10.0))
             del cat0
@@ -209,57 +417,56 @@ def main():
     n_visible = int(os.environ.get("MCD_VISIBLE_DEVICES", "0")) or None      # testing aid: fold ranks onto fewer devices
     if n_visible:
         local_rank = local_rank % n_visible
-    dist = None
+    group, comm = None, None
     if world > 1:
-        import torch.distributed as dist           # host-side rendezvous only (gloo); the data path is RCCL in the library
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        rccl_note = "ncclAllReduce(sum, f64, count = walkers) per step on the catalogue stream"
+        from mcmc_dynamics_amd.hostgroup import HostGroup, HostGroupError
         try:
-            uid = [native.Context.unique_id() if rank == 0 else None]
-        except native.NativeError as exc:
-            uid = [None]
-            rccl_note = "unavailable: {0}".format(exc)
-        dist.broadcast_object_list(uid, src=0)
+            group = HostGroup(rank, world, timeout=COLLECTIVE_TIMEOUT_S + 60)
+        except HostGroupError as exc:
+            fail_collective(rank, world, args, "host rendezvous", repr(exc))
+        # rank 0's RCCL unique id -> every rank -> ncclCommInitRank; all ranks learn whether everybody succeeded
+        uid, err = b"", ""
+        if rank == 0:
+            try:
+                uid = native.Context.unique_id()
+            except native.NativeError as exc:
+                err = str(exc)
         try:
-            if uid[0] is None:
-                raise native.NativeError("no RCCL unique id")
-            ctx = native.Context(rank=rank, n_ranks=world, unique_id=uid[0], device=local_rank)
-            ok = 1
-        except native.NativeError as exc:
-            ok = 0
-            rccl_note = "unavailable: {0}".format(exc)
-        import torch
-        flag = torch.tensor([ok], dtype=torch.int64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            # Degraded mode (recorded in the JSON line): every rank still evaluates its own star shard and the per-walker
-            # partial sums are exchanged over the host process group instead (see the timed loop).
-            if ok:
-                ctx.close()
-            ctx = native.Context(n_devices=1, device_ids=[local_rank])
-            if not rccl_note.startswith("unavailable"):
-                rccl_note = "unavailable on another rank"
+            uid = group.bcast_bytes(uid, src=0)
+            ctx = None
+            if len(uid) == native.UNIQUE_ID_BYTES:
+                try:
+                    ctx = native.Context(rank=rank, n_ranks=world, unique_id=uid, device=local_rank)
+                except native.NativeError as exc:
+                    err = str(exc)
+            ok = int(group.allreduce(np.array([1 if ctx is not None else 0], dtype=np.int64), op="min")[0])
+            errs = group.bcast_json(err, src=0) if ok == 0 else ""
+        except HostGroupError as exc:
+            fail_collective(rank, world, args, "communicator set-up", repr(exc))
+        if not ok:
+            fail_collective(rank, world, args, "ncclCommInitRank", err or errs or "failed on another rank")
+        comm = ctx.comm_info()
+        sizes = group.allreduce(np.array([comm["size"], -comm["size"]], dtype=np.int64), op="max")
+        if int(sizes[0]) != world or int(sizes[1]) != -world or comm["rank"] != rank:
+            fail_collective(rank, world, args, "communicator check",
+                            "ncclCommCount / ncclCommUserRank report {0}, expected size {1} rank {2}".format(comm, world, rank))
     else:
-        rccl_note = None
         ctx = native.Context(n_devices=1, device_ids=[local_rank])
+        comm = ctx.comm_info()
 
     # ---- synthetic catalogue shard of this rank; identical walkers on every rank
     if strong:
-        full = synthetic.make_catalog(n_stars, config=config, background=(model != "const"))
-        lo, hi = n_stars * rank // world, n_stars * (rank + 1) // world
-        cat = {k: (v[lo:hi] if isinstance(v, np.ndarray) else v) for k, v in full.items()}
-        del full
+        from mcmc_dynamics_amd import distributed
+        lo, hi = distributed.shard_bounds(n_stars, rank, world)
+        cat = synthetic.make_catalog_range(n_stars, lo, hi, config=config, background=(model != "const"))
         total_stars = n_stars
     else:
         cat = synthetic.make_catalog(n_stars, config=config, seed=synthetic.CATALOG_SEED_BASE + config + 1000 * rank,
                                      background=(model != "const"))
         total_stars = n_stars * world
     truth = cat["truth"]
-    if dist is not None and not strong:              # walkers are drawn around rank 0's truth everywhere
-        box = [truth if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        truth = box[0]
-    names = ["v_sys", "sigma_max", "v_maxx", "v_maxy"] + (["v_back", "sigma_back", "f_back"] if model == "bggauss" else [])
+    if group is not None and not strong:             # walkers are drawn around rank 0's truth everywhere
+        truth = group.bcast_json(truth, src=0)
     pos = synthetic.make_walkers(n_walkers, names, truth, config=config)
     if model == "profile":              # insert a (30 arcsec) and r_peak (60 arcsec) balls: run_tests.py:36-37
         rng_m = np.random.default_rng(synthetic.WALKER_SEED_BASE + 100 + config)
@@ -280,101 +487,30 @@ def main():
         pos = np.ascontiguousarray(np.broadcast_to(pos, (n_bins,) + pos.shape))
         bytes_per_term = bytes_per_term if args.precision == "f64" else bytes_per_term // 2
 
-    gpu_cat = build_catalog(native, ctx, synthetic, None, cat, model, args.precision, bin_offsets)
+    gpu_cat = build_catalog(native, ctx, synthetic, cat, model, args.precision, bin_offsets)
     gpu_cat.upload_params(pos)
-    abandoned = None
-    if dist is not None and not rccl_note.startswith("unavailable"):
-        # Watchdog for the first collective (RCCL builds its xGMI rings lazily inside it): a rank whose all-reduce has
-        # not completed after COLLECTIVE_TIMEOUT_S abandons that context and every rank drops to the degraded mode, so
-        # that a fabric problem yields a marked bench line instead of a hung job.
-        import threading
-        import torch
-        done = threading.Event()
+    if group is not None:
+        first_collective(gpu_cat, group, rank, world, args)
 
-        def first_step():
-            gpu_cat.enqueue()
-            gpu_cat.sync()
-            done.set()
-        worker = threading.Thread(target=first_step, daemon=True)
-        worker.start()
-        worker.join(COLLECTIVE_TIMEOUT_S)
-        flag = torch.tensor([1 if done.is_set() else 0], dtype=torch.int64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            abandoned = (gpu_cat, ctx)                   # never closed: its stream may be blocked for good
-            rccl_note = "unavailable: first all-reduce did not complete within {0} s on some rank".format(COLLECTIVE_TIMEOUT_S)
-            ctx = native.Context(n_devices=1, device_ids=[local_rank])
-            gpu_cat = build_catalog(native, ctx, synthetic, None, cat, model, args.precision, bin_offsets)
-            gpu_cat.upload_params(pos)
-    gpu_cat.set_option("timing", 2)
-    gpu_cat.set_option("timing_reserve", min(65536, max(args.steps, args.warmup)))   # no hipEventCreate inside the timed region
-    # the event pair costs ~6 us per step between back-to-back kernels (tools/event_cost_probe.py): the kernel time is
-    # sampled on every 8th launch of the timed region, not on each
-    stride = 8 if args.steps >= 64 else 1
-    gpu_cat.set_option("timing_stride", stride)
-
-    def barrier():
-        gpu_cat.sync()
-        if dist is not None:
-            dist.barrier()
-
-    # Clock ramp (untimed, before the W warm-up steps): the GPU needs some 100 ms of load to reach its sustained clocks --
-    # measured kernel time 270 us in the first 20 launches after idle, 222 us once settled.  Every rank runs the same
-    # number of launches (the all-reduce is collective).
-    ramp_steps = 0
-    if args.clock_ramp_seconds > 0:
-        gpu_cat.enqueue()
-        gpu_cat.sync()
-        t_r = time.perf_counter()
-        for _ in range(8):
-            gpu_cat.enqueue()
-        gpu_cat.sync()
-        per_step = max((time.perf_counter() - t_r) / 8, 1e-6)
-        ramp_steps = int(min(20000, args.clock_ramp_seconds / per_step))
-        if dist is not None:
-            import torch
-            t = torch.tensor([ramp_steps], dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ramp_steps = int(t[0])
-        for _ in range(ramp_steps):
-            gpu_cat.enqueue()
-    for _ in range(args.warmup):
-        gpu_cat.enqueue()
-    barrier()
-    gpu_cat.timing_collect()                         # drop ramp and warm-up launches
-
-    # Degraded mode (RCCL unavailable): the exchange is NOT skipped -- every step fetches the rank's partial sums and
-    # all-reduces them over the host process group (gloo), which serialises the steps; the JSON line says so.
-    host_exchange = dist is not None and rccl_note.startswith("unavailable")
-    t0 = time.perf_counter()
-    if host_exchange:
-        import torch
-        for _ in range(args.steps):
-            gpu_cat.enqueue()
-            part = torch.from_numpy(gpu_cat.fetch())
-            dist.all_reduce(part, op=dist.ReduceOp.SUM)
-    else:
-        for _ in range(args.steps):
-            gpu_cat.enqueue()
-    gpu_cat.sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    kernel_ms_total, n_launch = gpu_cat.timing_collect()
+    # HIP events around every 4th (K < 64) or 8th main-kernel launch of the timed region: an event pair costs two signal
+    # packets (~6 us per step between back-to-back kernels, tools/event_cost_probe.py), so the kernel time is sampled
+    stride = 8 if args.steps >= 64 else 4
+    try:
+        t = timed_steps(gpu_cat, group, args.steps, args.warmup, args.clock_ramp_seconds, stride)
+    except Exception as exc:
+        if group is None:
+            raise
+        fail_collective(rank, world, args, "timed region", repr(exc))
+    elapsed, kernel_s = t["elapsed"], t["kernel_s"]
     result = gpu_cat.fetch()
     info = gpu_cat.launch_info()
     info["kernel_family"] = {0: "plain", 1: "fast", 2: "fast, narrow-range variant", -1: "none"}[gpu_cat.fast_level]
 
-    # blocking C-ABI call (host params in, host results out) for the PCIe/sync-inclusive rate
-    gpu_cat.set_option("timing", 0)
-    t1 = time.perf_counter()
-    n_sync = max(5, min(50, args.steps))
-    for _ in range(n_sync):
-        gpu_cat.loglike(pos)
-    sync_call = (time.perf_counter() - t1) / n_sync
+    # blocking C-ABI call (host params in, host results out): the PCIe/sync-inclusive rate, never `value`
+    n_sync = max(20, min(50, args.steps))
+    sync_med, sync_mean = blocking_calls(gpu_cat, pos, n_sync)
+    if group is not None:
+        sync_med = float(group.allreduce(np.array([sync_med]), op="max")[0])
 
     # sampler-driven end-to-end rate (1 GPU only): the built-in stretch move makes two blocking calls of W/2
     # proposals per step, exactly the batching emcee's default move produces (hard parts)
@@ -404,61 +540,99 @@ def main():
                 "acceptance_fraction": float(np.mean(sampler.acceptance_fraction))}
         fit.close()
 
+    # per-rank figures of the headline workload, gathered before the catalogue goes away
+    kernel_us_ranks = [kernel_s * 1e6]
+    if group is not None:
+        kernel_us_ranks = [float(x[0]) for x in group.allgather_array(np.array([kernel_s * 1e6]))]
+    gpu_cat.close()
+
+    strong_rec = None
+    if args.workload == "c3" and not args.no_c4_strong and args.stars is None and args.walkers is None and args.precision == "f64":
+        try:
+            strong_rec = c4_strong(native, synthetic, ctx, group, rank, world, args)
+        except Exception as exc:
+            if group is not None:
+                fail_collective(rank, world, args, "c4_strong", repr(exc))
+            strong_rec = {"error": repr(exc)}
+
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        if abandoned is not None:
-            os._exit(0)                                  # skip destructors of the abandoned (possibly blocked) context
+        if group is not None:
+            group.barrier()
+            group.close()
         return
 
     terms_per_step = float(total_stars) * n_walkers
     value = terms_per_step * args.steps / elapsed
-    kernel_s = kernel_ms_total * 1e-3 / max(1, n_launch)
     local_terms = float(len(cat["v"])) * n_walkers
-    achieved = local_terms * bytes_per_term / kernel_s / 1e9
+    streaming_gbps = local_terms * bytes_per_term / kernel_s / 1e9
 
-    traffic = None                                    # PMC bytes per launch, measured for the default shape of a workload
+    traffic, traffic_src = None, None                # PMC bytes per launch: imported from the committed rocprofv3 passes
     if args.stars is None and args.walkers is None and args.precision == "f64" and not strong:
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(args.workload)
+                pmc = json.load(f)
+            traffic = pmc.get(args.workload)
+            traffic_src = ("imported, not collected in this run: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE per launch "
+                           "of this kernel from two rocprofv3 --pmc passes of this command ({0})".format(pmc.get("_provenance", "see profiles/README.md")))
         except Exception:
             pass
 
+    roofline = None
+    if args.precision == "f64":
+        isa_key = model if model in ("bgfixed", "bggauss") and info["kernel_family"].endswith("narrow-range variant") else \
+            (model + "_general" if model in ("bgfixed", "bggauss") else model)
+        row, src = isa_counts(isa_key)
+        if row is not None:
+            achieved = row["valu_per_term"] * local_terms / 64.0 / kernel_s
+            roofline = {
+                "bound": "valu_f64", "achieved": achieved, "peak": VALU_F64_PEAK, "unit": "VALU wave-instructions/s",
+                "frac": achieved / VALU_F64_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "mcd::loglike_kernel", "kernel_us": kernel_s * 1e6, "kernel_us_sampled_launches": t["kernel_samples"],
+                "kernel_us_first_20_launches_after_idle": t["cold_kernel_us"],
+                "valu_per_term": row["valu_per_term"], "valu_f64_per_term": row["f64_per_term"],
+                "valu_per_term_source": src, "terms_per_launch": local_terms,
+                "peak_definition": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 vector instruction",
+                "hbm_streaming_model": {"algorithmic_bytes_per_term": bytes_per_term, "GBps": streaming_gbps,
+                                        "frac_of_8TBps": streaming_gbps / HBM_PEAK_GBPS,
+                                        "note": "SURVEY 8(d): each walker's sum reads every star record once; one scalar record "
+                                                "load serves 64 walkers, so a figure > 1 means register reuse, not bandwidth"},
+                "hbm_measured": None if traffic is None else {
+                    "bytes_per_launch": traffic, "GBps": traffic / kernel_s / 1e9,
+                    "frac_of_8TBps": traffic / kernel_s / 1e9 / HBM_PEAK_GBPS},
+                "compulsory_bytes_per_launch": len(cat["v"]) * info["record_bytes"], "walker_tile": info["walker_tile"],
+                "note": "the kernel is bound by f64 vector-instruction issue (VALUBusy 97 %, profiles/): achieved = VALU "
+                        "wave-instructions of the hot loop per term x terms / 64 lanes / kernel time"}
+        else:
+            roofline = {"bound": "valu_f64", "achieved": None, "peak": VALU_F64_PEAK, "unit": "VALU wave-instructions/s",
+                        "frac": None, "traffic": traffic, "kernel_us": kernel_s * 1e6, "error": src}
+    else:
+        roofline = {"bound": "valu_f32", "achieved": None, "peak": None, "unit": "VALU wave-instructions/s", "frac": None,
+                    "traffic": None, "kernel_us": kernel_s * 1e6, "kernel_us_sampled_launches": t["kernel_samples"],
+                    "hbm_streaming_model": {"algorithmic_bytes_per_term": bytes_per_term, "GBps": streaming_gbps,
+                                            "frac_of_8TBps": streaming_gbps / HBM_PEAK_GBPS}}
+
     out = {
         "metric": "star-walker log-L terms/sec", "value": value, "unit": "terms/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": ramp_steps,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": t["ramp_steps"],
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "degraded": False,
         "config": {"workload": desc, "stars_per_gpu": len(cat["v"]), "stars_total": total_stars, "walkers": n_walkers,
-                   "likelihood": model, "parallelism": ("stars sharded over {0} rank(s); ".format(world) +
-                                   ("RCCL all-reduce of {0} doubles per step".format(n_walkers)
-                                    if rccl_note and not rccl_note.startswith("unavailable") else "RCCL unavailable: per-step exchange over the host process group (gloo all-reduce of the fetched partial sums)"))
-                   if world > 1 else "1 GPU"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "algorithmic_bytes_per_term": bytes_per_term, "kernel_us": kernel_s * 1e6,
-                     "kernel_us_sampled_launches": int(n_launch),
-                     "kernel": "mcd::loglike_kernel", "walker_tile": info["walker_tile"],
-                     "compulsory_bytes_per_launch": len(cat["v"]) * info["record_bytes"],
-                     "note": "streaming-model bytes (each walker's sum reads every star record once, SURVEY 8(d)); "
-                             "the kernel reuses one scalar record load for 64 walkers, so frac > 1 means register "
-                             "reuse and the binding resource is f64 VALU issue, not HBM"},
-        "valu_f64_model": None if args.precision != "f64" else {
-            "slots_per_term": VALU_SLOTS_PER_TERM[model], "slot_ns": VALU_SLOT_NS,
-            "predicted_kernel_us": VALU_SLOTS_PER_TERM[model] * VALU_SLOT_NS * (local_terms / 64) / N_SIMD * 1e-3,
-            "measured_over_predicted": kernel_s * 1e6 / (VALU_SLOTS_PER_TERM[model] * VALU_SLOT_NS * (local_terms / 64) / N_SIMD * 1e-3),
-            "note": "the kernel is bound by f64 vector-instruction issue; predicted = instruction mix of the inner loop "
-                    "priced at the measured issue rate of a fully occupied MI355X (prologue, final log and launch tail "
-                    "not included)"},
-        "hbm_algorithmic_GBps": value * bytes_per_term / 1e9,
-        "hbm_roofline_frac": value * bytes_per_term / 1e9 / HBM_PEAK_GBPS / world,
-        "sync_call_terms_per_s": local_terms * world / sync_call,
-        "sync_call_us": sync_call * 1e6,
+                   "likelihood": model,
+                   "parallelism": ("stars sharded over {0} ranks (one process per GPU); one ncclAllReduce(sum, f64, {1}) per step"
+                                   .format(world, n_walkers * n_bins) if world > 1 else "1 GPU")},
+        "roofline": roofline,
+        "kernel_us_per_rank": kernel_us_ranks,
+        "blocking_call_us_median": sync_med * 1e6, "blocking_call_us_mean": sync_mean * 1e6,
+        "blocking_call_terms_per_s": local_terms * world / sync_med,
         "launch": info,
         "mcmc_end_to_end": mcmc,
-        "collective": rccl_note,
+        "collective": None if world == 1 else {
+            "kind": "ncclAllReduce(sum, f64, count = {0}) per step; pipelined steps run it on a second HIP stream".format(n_walkers * n_bins),
+            "comm_size": comm["size"], "comm_rank_of_rank0": comm["rank"], "rccl_version": comm["rccl_version"],
+            "first_allreduce_watchdog_s": COLLECTIVE_TIMEOUT_S},
+        "libraries": mapped_libraries(),
+        "c4_strong": strong_rec,
     }
     out["dtype"] = {"f64": "f64", "f32": "f32", "f32acc64": "f32 terms, f64 accumulation"}[args.precision]
     if n_bins > 1:
@@ -476,11 +650,9 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if abandoned is not None:
-        os._exit(0)
+    if group is not None:
+        group.barrier()
+        group.close()
 
 
 if __name__ == "__main__":

@@ -60,8 +60,12 @@ typedef enum {
                                      (analysis/model.py:93-222)                                     */
     MCD_MODEL_PROFILE_BGGAUSS = 4,/* ModelFitGB: + per-walker Gaussian background, density prior
                                      (analysis/model.py:391-456)                                    */
-    MCD_MODEL_PROFILE_BGDENS = 5  /* ModelFitConstantBackground: fixed per-star background lnL, density prior
+    MCD_MODEL_PROFILE_BGDENS = 5, /* ModelFitConstantBackground: fixed per-star background lnL, density prior
                                      with per-walker f_back (analysis/model.py:565-623)             */
+    MCD_MODEL_PROFILE_BGFIXED = 6 /* ModelFit(background=Gaussian / SingleStars): the profiles of MCD_MODEL_PROFILE
+                                     with the fixed per-star background lnL and pmember mixture that
+                                     Runner._calculate_lnlike applies to every subclass
+                                     (analysis/model.py:182-222 -> analysis/runner.py:272-286)      */
 } mcd_model;
 
 typedef enum {
@@ -82,8 +86,8 @@ typedef struct {
     const double* dec;        /* deg  */
     const double* v;          /* km/s */
     const double* verr;       /* km/s */
-    const double* lnlike_bg;  /* CONST_BGFIXED, PROFILE_BGDENS: background(v, verr) per star       */
-    const double* pmember;    /* CONST_BGFIXED: prior membership probability                       */
+    const double* lnlike_bg;  /* CONST_BGFIXED, PROFILE_BGFIXED, PROFILE_BGDENS: background(v, verr) per star */
+    const double* pmember;    /* CONST_BGFIXED, PROFILE_BGFIXED: prior membership probability      */
     const double* density;    /* *_BGGAUSS, PROFILE_BGDENS: normalised stellar surface density     */
     int32_t model;            /* mcd_model     */
     int32_t centre;           /* mcd_centre    */
@@ -129,7 +133,7 @@ int mcd_catalog_destroy(mcd_catalog* cat);
 /* Number of columns K of the resolved parameter table expected by mcd_loglike_batch:
  *   CONST    : v_sys, sigma_max, v_maxx, v_maxy [, ra_center, dec_center]
  *   *_BGGAUSS: ... + v_back, sigma_back, f_back
- *   PROFILE  : v_sys, sigma_max, a, v_maxx, v_maxy, r_peak [, ra_center, dec_center] (a, r_peak in arcsec)
+ *   PROFILE, PROFILE_BGFIXED: v_sys, sigma_max, a, v_maxx, v_maxy, r_peak [, ra_center, dec_center] (a, r_peak in arcsec)
  *   PROFILE_BGGAUSS: ... + v_back, sigma_back, f_back        PROFILE_BGDENS: ... + f_back
  * (order of config/constant.json:6-11, constant_with_background.json:6-14, model_with_background.json:6-16;
  * config/model.json interleaves the centre between v_maxx and v_maxy -- the host maps columns by name). */

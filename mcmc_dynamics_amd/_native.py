@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCD_LIB_PATH") or os.path.join(_HERE, "libmcd_hip.so")
 
 MODEL_CONST, MODEL_CONST_BGFIXED, MODEL_CONST_BGGAUSS = 0, 1, 2
-MODEL_PROFILE, MODEL_PROFILE_BGGAUSS, MODEL_PROFILE_BGDENS = 3, 4, 5
+MODEL_PROFILE, MODEL_PROFILE_BGGAUSS, MODEL_PROFILE_BGDENS, MODEL_PROFILE_BGFIXED = 3, 4, 5, 6
 CENTRE_FIXED, CENTRE_FREE = 0, 1
 F64, F32, F32_ACC64 = 0, 1, 2
 PRECISIONS = {"f64": F64, "f32": F32, "f32acc64": F32_ACC64}
@@ -159,6 +159,7 @@ class Context(object):
             _check(self.lib, rc, "mcd_ctx_create")
             self.rank, self.n_ranks = 0, 1
         self.handle = handle
+        self.host_group = None                    # hostgroup.HostGroup of a multi-rank job (distributed.rank_context)
         self._catalogs = weakref.WeakSet()        # catalogues living on this context: closed before it
         _live_contexts.add(self)
 

@@ -15,6 +15,7 @@ import logging
 import numpy as np
 
 from .. import _native, units
+from ..background import SingleStars
 from ..parameter import Parameter, Parameters
 from ..utils.coordinates import calc_xy_offset, get_amplitude_and_angle
 from ..utils.data_reader import ColumnTable
@@ -101,8 +102,16 @@ class ModelFit(Runner):
         x_pa = r * np.sin(np.arctan2(dy, dx) - theta_0)
         return v_sys + 2. * (v_max / r_peak) * x_pa / (1. + (r / r_peak) ** 2)
 
+    def _catalog_model(self):
+        # ModelFit.lnlike ends in Runner._calculate_lnlike (model.py:222 -> runner.py:240-286): with a fixed `background`
+        # the pmember mixture applies to the profile models exactly as it does to ConstantFit
+        if self.lnlike_background is not None:
+            return _native.MODEL_PROFILE_BGFIXED, {"lnlike_bg": self.lnlike_background, "pmember": self.pmember}
+        return self._model_id, {}
+
     def lnlike(self, values):
-        """Log-likelihood of the data for one parameter vector (model.py:182-222)."""
+        """Log-likelihood of the data for one parameter vector (model.py:182-222), including the fixed background
+        population when one was given (runner.py:272-286)."""
         return super(ModelFit, self).lnlike(values)
 
     # ------------------------------------------------------------------ post-processing
@@ -199,7 +208,11 @@ class ModelFitConstantBackground(ModelFit):
         self.density = None
         super(ModelFitConstantBackground, self).__init__(data=data, parameters=parameters, **kwargs)
         self.background = background
-        self.lnlike_background = np.asarray(self.background(self.v, self.verr), dtype=np.float64)
+        if isinstance(background, SingleStars):            # O(N M) kernel-density precompute: on this rank's device
+            lnbg = self.background(self.v, self.verr, context=kwargs.get("context"))
+        else:
+            lnbg = self.background(self.v, self.verr)
+        self.lnlike_background = np.asarray(lnbg, dtype=np.float64)
 
     def _catalog_model(self):
         return self._model_id, {"lnlike_bg": self.lnlike_background, "density": self.density}

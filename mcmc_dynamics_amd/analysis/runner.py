@@ -272,6 +272,8 @@ class Runner(object):
         """(W, P) -> (W,) log-posteriors.  Walkers outside the prior get -inf; their rows are replaced by
         a valid row for the launch and masked afterwards (the reference skips the evaluation)."""
         values = np.atleast_2d(np.asarray(values, dtype=np.float64))
+        if self._context is not None and getattr(self._context, "n_ranks", 1) > 1:
+            self._check_ranks_agree(values)
         plan = self._plan()
         if plan.direct_cols is not None and values.shape[1] == plan.free_idx.size:
             ok = plan.prior_ok_free(values)
@@ -321,6 +323,32 @@ class Runner(object):
         out[ok] = ll[ok] + lp[ok]
         return out
 
+    # ------------------------------------------------------------------ several ranks (one process per GPU)
+    RANK_CHECK_EVERY = 256
+
+    def _rank_group(self):
+        """Host group of a multi-rank context (``distributed.rank_context``), None for a single process."""
+        ctx = self._context
+        if ctx is None or getattr(ctx, "n_ranks", 1) <= 1:
+            return None
+        group = getattr(ctx, "host_group", None)
+        if group is None:
+            raise RuntimeError("this Runner sits on a multi-rank context without a host group: create the context with "
+                               "mcmc_dynamics_amd.distributed.rank_context(), which keeps the group for the start-up hand-offs")
+        return group
+
+    def _check_ranks_agree(self, values):
+        """The all-reduce at the end of every evaluation adds the ranks' partial sums row by row: it is only meaningful
+        when every rank passes the SAME (W, P) table.  Verified on the first call and every RANK_CHECK_EVERY-th call
+        (a CRC over the host group); a mismatch raises instead of producing a silently wrong chain."""
+        n = getattr(self, "_n_rank_batches", 0)
+        self._n_rank_batches = n + 1
+        if n % self.RANK_CHECK_EVERY:
+            return
+        if not self._rank_group().same_everywhere(values):
+            raise RuntimeError("the ranks of this job evaluate different walker tables: their partial log-likelihoods must not "
+                               "be summed (seed every rank's sampler identically, e.g. through Runner.__call__)")
+
     # ------------------------------------------------------------------ sampler driver
     def get_initials(self, n_walkers):
         """Initial positions from each free parameter's ``initials`` recipe (runner.py:308-330)."""
@@ -336,7 +364,10 @@ class Runner(object):
     def _make_sampler(self, n_walkers, seed=None):
         try:
             import emcee
-            return emcee.EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True)
+            sampler = emcee.EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True)
+            if seed is not None:
+                sampler._random.seed(seed)
+            return sampler
         except ImportError:
             from ..sampler import EnsembleSampler
             return EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True, seed=seed)
@@ -363,13 +394,20 @@ class Runner(object):
         else:
             pos = self.get_initials(n_walkers=n_walkers)
 
+        # Several ranks (stars sharded, one process per GPU): rank 0's start positions and one sampler seed go to every
+        # rank, so that all of them propose the same walkers at every step (the reference has one process, runner.py:403).
+        group, seed = self._rank_group(), None
+        if group is not None:
+            pos = group.bcast_array(pos, src=0)
+            seed = int(group.bcast_json(int(np.random.SeedSequence().entropy % (2 ** 32)), src=0))
+
         lp0 = self.lnprior_batch(pos)
         for i in range(n_walkers):
             if not np.isfinite(lp0[i]):
                 raise ValueError("Invalid initial guesses for walker {0}: {1}={2}".format(
                     i, self.fitted_parameters, pos[i]))                                      # runner.py:392-395
 
-        sampler = self._make_sampler(n_walkers)
+        sampler = self._make_sampler(n_walkers, seed=seed)
         logger.info("Running MCMC chain ...")
         if n_out is not None:
             logger.info("Iter. <log like>   " + "".join(" {0:12s}".format("<" + n + ">") for n in self.fitted_parameters))

@@ -678,7 +678,7 @@ int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** ou
 
 static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::unique_ptr<mcd_catalog>& cat) {
     if (d->n_stars < 0) return fail(MCD_ERR_INVALID, "negative n_stars");
-    if (d->model < 0 || d->model > MCD_MODEL_PROFILE_BGDENS) return fail(MCD_ERR_INVALID, "unknown model");
+    if (d->model < 0 || d->model >= mcd::kNumModels) return fail(MCD_ERR_INVALID, "unknown model");
     const int bgk = mcd::bg_kind(d->model);
     if (d->centre != MCD_CENTRE_FIXED && d->centre != MCD_CENTRE_FREE) return fail(MCD_ERR_INVALID, "unknown centre mode");
     if (d->precision < MCD_F64 || d->precision > MCD_F32_ACC64) return fail(MCD_ERR_INVALID, "unknown precision");

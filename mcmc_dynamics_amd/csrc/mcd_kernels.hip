@@ -369,6 +369,7 @@ hipError_t launch_loglike(hipStream_t s, const LaunchShape& sh, const void* reco
         MCD_DISPATCH(MODEL_PROFILE)
         MCD_DISPATCH(MODEL_PROFILE_BGGAUSS)
         MCD_DISPATCH(MODEL_PROFILE_BGDENS)
+        MCD_DISPATCH(MODEL_PROFILE_BGFIXED)
     }
 #undef MCD_DISPATCH
     return hipErrorInvalidValue;
@@ -426,6 +427,7 @@ hipError_t launch_per_star(hipStream_t s, const LaunchShape& sh, const void* rec
         case MODEL_BGGAUSS: return per_star_model<MODEL_BGGAUSS>(s, sh, records, n, wpar_row, mode, out);
         case MODEL_PROFILE_BGGAUSS: return per_star_model<MODEL_PROFILE_BGGAUSS>(s, sh, records, n, wpar_row, mode, out);
         case MODEL_PROFILE_BGDENS: return per_star_model<MODEL_PROFILE_BGDENS>(s, sh, records, n, wpar_row, mode, out);
+        case MODEL_PROFILE_BGFIXED: return per_star_model<MODEL_PROFILE_BGFIXED>(s, sh, records, n, wpar_row, mode, out);
     }
     return hipErrorInvalidValue;
 }

@@ -24,6 +24,13 @@
 #else
 #define MCD_HD inline
 #endif
+// An empty volatile asm keeps the compiler from turning a small wave-uniform `if` into per-lane selects (v_cndmask on
+// every iteration): the block stays behind a scalar branch.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MCD_KEEP_BRANCH() asm volatile("")
+#else
+#define MCD_KEEP_BRANCH() ((void)0)
+#endif
 
 namespace mcd {
 
@@ -46,14 +53,16 @@ enum WalkerSlot : int {
 // (constant.py:326-364, model.py:391-456), fixed per-star lnL + density prior with per-walker f_back (model.py:565-623).
 enum Model : int {
     MODEL_CONST = 0, MODEL_BGFIXED = 1, MODEL_BGGAUSS = 2,
-    MODEL_PROFILE = 3, MODEL_PROFILE_BGGAUSS = 4, MODEL_PROFILE_BGDENS = 5
+    MODEL_PROFILE = 3, MODEL_PROFILE_BGGAUSS = 4, MODEL_PROFILE_BGDENS = 5,
+    MODEL_PROFILE_BGFIXED = 6          // ModelFit(background=...): profile cluster part + the pmember mixture of runner.py:272-286
 };
+constexpr int kNumModels = 7;
 enum Background : int { BG_NONE = 0, BG_FIXED = 1, BG_GAUSS = 2, BG_FIXED_DENSITY = 3 };
 
 MCD_HD constexpr bool is_profile(int model) { return model >= MODEL_PROFILE; }
 MCD_HD constexpr int bg_kind(int model) {
     return (model == MODEL_CONST || model == MODEL_PROFILE) ? BG_NONE
-           : (model == MODEL_BGFIXED) ? BG_FIXED
+           : (model == MODEL_BGFIXED || model == MODEL_PROFILE_BGFIXED) ? BG_FIXED
            : (model == MODEL_PROFILE_BGDENS) ? BG_FIXED_DENSITY : BG_GAUSS;
 }
 
@@ -410,6 +419,9 @@ MCD_HD double rcp_nr(double x) {
 // i.e. 1e-15 of |lnL| -- inside the rounding error of the reference's own float64 summation.  The factor 2 is free:
 // callers scale the variance they pass (m = 8 n gives (2 n)^-1/2).  Two instructions fewer than rsqrt_nr.
 MCD_HD double rsqrt2_newton(double m) {
+#if defined(MCD_AB_NEWTON3)                       // A/B builds only (csrc/Makefile: variant): the third-order form, for timing
+    return 2.0 * rsqrt_nr(m);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(m);
 #else
@@ -809,14 +821,12 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         };
         const int n4 = count >> 2;
         if constexpr (NARROW) {
-            // eight raw factors per rescale: two 4-star groups (one scalar record-load batch each) between rescales
-            const int n8 = n4 >> 1;
-            for (int g = 0; g < n8; ++g) {
-#pragma nounroll
-                for (int h = 0; h < 2; ++h, r += 4 * ND) four(r);
-                acc.rescale_narrow();
+            // eight raw factors per rescale: every second 4-star group (one scalar record-load batch each)
+            for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                four(r);
+                if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_narrow(); }    // wave-uniform: a scalar branch, not a select
             }
-            if (n4 & 1) { four(r); r += 4 * ND; acc.rescale_narrow(); }
+            if (n4 & 1) acc.rescale_narrow();
         } else {
             for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale(); }
         }
@@ -844,13 +854,11 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         };
         const int n4 = count >> 2;
         if constexpr (NARROW) {
-            const int n8 = n4 >> 1;
-            for (int g = 0; g < n8; ++g) {
-#pragma nounroll
-                for (int h = 0; h < 2; ++h, r += 4 * ND) four(r);
-                acc.rescale_density_narrow();
+            for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                four(r);
+                if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_density_narrow(); }    // wave-uniform: a scalar branch, not a select
             }
-            if (n4 & 1) { four(r); r += 4 * ND; acc.rescale_density_narrow(); }
+            if (n4 & 1) acc.rescale_density_narrow();
         } else {
             for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale_density(); }
         }
@@ -883,13 +891,11 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         };
         const int n4 = count >> 2;
         if constexpr (NARROW) {
-            const int n8 = n4 >> 1;
-            for (int g = 0; g < n8; ++g) {
-#pragma nounroll
-                for (int h = 0; h < 2; ++h, r += 4 * ND) four(r);
-                acc.rescale_narrow();
+            for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                four(r);
+                if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_narrow(); }    // wave-uniform: a scalar branch, not a select
             }
-            if (n4 & 1) { four(r); r += 4 * ND; acc.rescale_narrow(); }
+            if (n4 & 1) acc.rescale_narrow();
         } else {
             for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale(); }
         }

@@ -219,7 +219,7 @@ class HostGroup(object):
     def allreduce(self, array, op="sum"):
         """Element-wise sum / max / min over the ranks of a float64 or int64 array (or scalar); same result on every
         rank, combined in rank order."""
-        a = np.ascontiguousarray(array)
+        a = np.asarray(array, order="C")                    # (ascontiguousarray would turn a scalar into shape (1,))
         code = "i8" if a.dtype.kind in "iub" else "f8"
         a = a.astype(_DTYPES[code], copy=False)
         fn = {"sum": np.add, "max": np.maximum, "min": np.minimum}[op]

@@ -97,6 +97,53 @@ def make_catalog(n_stars, config=2, seed=None, background=False, r_max_arcsec=30
     return cat
 
 
+BLOCK_STARS = 125000
+
+
+def make_catalog_range(n_total, lo, hi, config=4, background=False, block=BLOCK_STARS):
+    """Stars [lo, hi) of an ``n_total``-star catalogue that is defined block by block (``block`` stars per block, block b
+    seeded with (CATALOG_SEED_BASE + config, b)), so that every rank of a sharded run generates only its own part of
+    the SAME catalogue whatever the number of ranks (strong scaling, C4).  Same recipe as ``make_catalog``; the
+    rotation axis is that of block 0's generator."""
+    n_total, lo, hi = int(n_total), int(lo), int(hi)
+    if not 0 <= lo <= hi <= n_total:
+        raise ValueError("range [{0}, {1}) outside catalogue of {2} stars".format(lo, hi, n_total))
+    base = CATALOG_SEED_BASE + int(config)
+    truth = make_catalog(1, config=config, seed=base, background=background)["truth"]
+    parts = []
+    for b in range(lo // block, (max(hi, lo + 1) - 1) // block + 1):
+        b0, b1 = b * block, min(n_total, (b + 1) * block)
+        if b1 <= b0:
+            break
+        cat = _catalog_with_axis(b1 - b0, np.random.default_rng([base, b]), truth["theta_0"], background)
+        s0, s1 = max(lo, b0) - b0, min(hi, b1) - b0
+        parts.append({k: v[s0:s1] for k, v in cat.items()})
+    keys = parts[0].keys() if parts else ("ra", "dec", "v", "verr")
+    out = {k: (np.concatenate([p[k] for p in parts]) if parts else np.empty(0)) for k in keys}
+    out["truth"] = truth
+    return out
+
+
+def _catalog_with_axis(n, rng, theta_0, background, r_max_arcsec=300.0):
+    sigma, v_max = TRUTH["sigma_max"], TRUTH["v_max"]
+    r_max = r_max_arcsec / 60.0
+    sep = _truncated_halfnormal(rng, r_max / 2.0, r_max, n)
+    theta = rng.uniform(-np.pi, np.pi, size=n)
+    ra, dec = offsets_to_radec(sep * np.cos(theta), sep * np.sin(theta), CENTER_RA_DEG, CENTER_DEC_DEG)
+    v = TRUTH["v_sys"] + v_max * np.sin(theta - theta_0) + rng.normal(scale=sigma, size=n)
+    verr = 0.1 * sigma * rng.lognormal(0.0, 0.5, size=n)
+    v = v + rng.normal(size=n) * verr
+    cat = {"ra": ra, "dec": dec, "v": v, "verr": verr}
+    if background:
+        is_back = rng.random(n) < 0.2
+        v_back = rng.normal(TRUTH["v_back"], TRUTH["sigma_back"], size=n) + rng.normal(size=n) * verr
+        cat["v"] = np.where(is_back, v_back, v)
+        density = np.clip(np.exp(-sep * sep / (2.0 * (r_max / 3.0) ** 2)), 0.02, 1.0)
+        cat["density"] = density
+        cat["pmember"] = density / (density + TRUTH["f_back"])
+    return cat
+
+
 # prior bounds of config/constant.json and config/constant_with_background.json (:6-14)
 BOUNDS = {"v_sys": (-np.inf, np.inf), "sigma_max": (0.0, np.inf), "v_maxx": (-np.inf, np.inf),
           "v_maxy": (-np.inf, np.inf), "ra_center": (0.0, 360.0), "dec_center": (-90.0, 90.0),

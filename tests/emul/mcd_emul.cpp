@@ -88,11 +88,11 @@ extern "C" int emul_kd() { return KD; }
 extern "C" int emul_loglike(int model, int free_centre, int fast, int64_t n, const double* recs, const double* wpar,
                             int64_t W, int64_t chunk_len, double* out) {
 #define CASE(M, F, X) if (model == M && (free_centre != 0) == F && (fast != 0) == X && fast != 2) { run<M, F, X ? 1 : 0>(n, recs, wpar, W, chunk_len, out); return 0; }
-    FOR_ALL(0) FOR_ALL(1) FOR_ALL(2) FOR_ALL(3) FOR_ALL(4) FOR_ALL(5)
+    FOR_ALL(0) FOR_ALL(1) FOR_ALL(2) FOR_ALL(3) FOR_ALL(4) FOR_ALL(5) FOR_ALL(6)
 #undef CASE
     if (fast == 2) {                          // narrow-range variants
 #define NARROW_CASE(M) if (model == M) { if (free_centre) run<M, true, 2>(n, recs, wpar, W, chunk_len, out); else run<M, false, 2>(n, recs, wpar, W, chunk_len, out); return 0; }
-        NARROW_CASE(1) NARROW_CASE(2) NARROW_CASE(4) NARROW_CASE(5)
+        NARROW_CASE(1) NARROW_CASE(2) NARROW_CASE(4) NARROW_CASE(5) NARROW_CASE(6)
 #undef NARROW_CASE
     }
     return -1;
@@ -101,7 +101,7 @@ extern "C" int emul_loglike(int model, int free_centre, int fast, int64_t n, con
 extern "C" int emul_per_star(int model, int free_centre, int mode, int64_t n, const double* recs, const double* wrow,
                              double* out) {
 #define CASE(M, F, X) if (X && model == M && (free_centre != 0) == F) { per_star<M, F>(n, recs, wrow, mode, out); return 0; }
-    FOR_ALL(1) FOR_ALL(2) FOR_ALL(4) FOR_ALL(5)
+    FOR_ALL(1) FOR_ALL(2) FOR_ALL(4) FOR_ALL(5) FOR_ALL(6)
 #undef CASE
     return -1;
 }
@@ -225,7 +225,7 @@ extern "C" int emul_sharded_loglike(int model, int free_centre, int level, int64
                                     int64_t target_waves, int tail_split, double* out, int64_t* n_general) {
     const std::vector<int64_t> ex(exc, exc + n_exc);
 #define CASE(M, F, X) if (X && model == M && (free_centre != 0) == F) { sharded<M, F>(level, n, recs, n_psets, bin_offsets, lnbg, ex, W, wpar, n_shards, target_waves, tail_split, out, n_general); return 0; }
-    FOR_ALL(0) FOR_ALL(1) FOR_ALL(2) FOR_ALL(3) FOR_ALL(4) FOR_ALL(5)
+    FOR_ALL(0) FOR_ALL(1) FOR_ALL(2) FOR_ALL(3) FOR_ALL(4) FOR_ALL(5) FOR_ALL(6)
 #undef CASE
     return -1;
 }

@@ -35,8 +35,8 @@ def lib():
     return _lib
 
 
-PROFILE_MODELS = (3, 4, 5)
-BG_OF = {0: 0, 1: 1, 2: 2, 3: 0, 4: 2, 5: 3}
+PROFILE_MODELS = (3, 4, 5, 6)
+BG_OF = {0: 0, 1: 1, 2: 2, 3: 0, 4: 2, 5: 3, 6: 1}
 
 
 def pack_records(cat, model, centre):

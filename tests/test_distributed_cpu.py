@@ -1,8 +1,10 @@
-"""world_size-2 (and 3) gloo runs of the sharded path on the CPU."""
+"""world_size-2 (and 3) runs of the sharded path on the CPU: the torch-free host group (what bench.py and
+``distributed.rank_context`` use) under the driver's launcher, and gloo as a second, independent all-reduce."""
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -30,3 +32,53 @@ def test_sharded_sum_equals_unsharded_gloo(world):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "DIST_OK world={0}".format(world) in res.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_group_under_the_drivers_launcher(world):
+    """HostGroup rendezvous + collectives + a Runner on a rank context, launched exactly as the driver launches bench.py."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29521 + world), os.path.join(ROOT, "tests", "hostgroup_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert "HOSTGROUP_OK world={0}".format(world) in res.stdout
+
+
+def test_host_group_explicit_port_and_failure_modes(tmp_path):
+    """MCD_RDZV_PORT mode (multi-node style) with plain subprocesses; a missing rank is a HostGroupError after the timeout,
+    not a hang; mismatched collectives are detected."""
+    import socket
+    import textwrap
+    from mcmc_dynamics_amd.hostgroup import HostGroup, HostGroupError
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, {root!r})
+        from mcmc_dynamics_amd.hostgroup import HostGroup
+        g = HostGroup.from_env(timeout=60)
+        x = g.allreduce(np.array([1.0 + g.rank, 10.0]), op="sum")
+        assert x[0] == sum(1.0 + r for r in range(g.world)) and x[1] == 10.0 * g.world
+        assert float(g.allreduce(3.5 * (g.rank + 1), op="max")) == 3.5 * g.world
+        g.barrier()
+        print("OK", g.rank)
+        g.close()
+    """).format(root=ROOT)
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="1", MCD_RDZV_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert sorted(o[0].strip() for o in outs) == ["OK 0", "OK 1", "OK 2"]
+    # single-rank group needs no sockets at all
+    g = HostGroup(0, 1)
+    assert float(g.allreduce(2.0, op="sum")) == 2.0 and g.bcast_bytes(b"x") == b"x" and g.same_everywhere(np.arange(3))
+    # rank 0 alone in a world of 2: rendezvous times out with an error
+    env = {"MASTER_PORT": "7", "MCD_RDZV_FILE": str(tmp_path / "rdzv.json")}
+    with pytest.raises(HostGroupError):
+        HostGroup(0, 2, timeout=1.0, env=env)
+    with pytest.raises(HostGroupError):
+        HostGroup(1, 2, timeout=1.0, env=env)          # stale rendezvous file of the dead hub: no connection, error

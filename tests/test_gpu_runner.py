@@ -201,6 +201,45 @@ def test_model_fit_constant_background(which):
     assert np.max(np.abs(mc.dispersion_model(named["sigma_max"], named["ra_center"], named["dec_center"], named["a"]) - sig)) < 1e-10
 
 
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit_with_fixed_background(which):
+    """ModelFit(data, background=Gaussian(...)): the reference's ModelFit.lnlike ends in Runner._calculate_lnlike, which
+    applies the pmember mixture to every subclass (model.py:222 -> runner.py:272-286).  Golden values from the reference."""
+    from mcmc_dynamics_amd import Gaussian, _native
+    from mcmc_dynamics_amd.analysis import ModelFit
+    g = load_golden("model_fit_bg_gaussian_" + which)
+    mf = ModelFit(_reader(g, ("pmember",)), background=Gaussian(float(g["bg_mean"]), float(g["bg_sigma"])))
+    if which == "fixed":
+        _fix(mf, g)
+    assert mf.fitted_parameters == [str(n) for n in g["names"]]
+    assert mf._catalog_model()[0] == _native.MODEL_PROFILE_BGFIXED
+    assert np.max(np.abs(mf.lnlike_background - g["lnlike_background"])) < 1e-12
+    assert rel_err(mf.lnprob_batch(g["values"]), g["lnprob"]) < RTOL                 # includes the -inf row
+    assert rel_err(np.array([mf.lnprob(row) for row in g["values"][:3]]), g["lnprob"][:3]) < RTOL
+    ok = np.isfinite(g["lnprob"])
+    mf._catalog.set_option("fast_path", 0)                                             # the plain kernels agree as well
+    assert rel_err(mf.lnlike_batch(g["values"][ok]), g["lnprob"][ok]) < RTOL
+    # without the background the same class evaluates the plain profile model: a different number
+    plain = ModelFit(_reader(g))
+    if which == "fixed":
+        _fix(plain, g)
+    assert np.all(np.abs(plain.lnlike_batch(g["values"][ok]) - g["lnprob"][ok]) > 1.0)
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit_gb_membership_matches_reference(which):
+    """ModelFitGB.calculate_membership_probabilities(chain, n_burn) (model.py:458-510) against the reference's output."""
+    from mcmc_dynamics_amd.analysis import ModelFitGB
+    g = load_golden("model_fit_gb_membership_" + which)
+    mg = ModelFitGB(_reader(g, ("density",)))
+    if which == "fixed":
+        _fix(mg, g)
+    assert mg.fitted_parameters == [str(n) for n in g["names"]]
+    got = mg.calculate_membership_probabilities(g["chain"], n_burn=int(g["n_burn"]))
+    assert got.shape == g["membership"].shape and np.max(np.abs(got - g["membership"])) < 1e-11
+    assert np.array_equal([mg.parameters[str(n)].value for n in g["names"]], g["median"])
+
+
 def test_model_fit_profiles_and_full_size():
     """create_profiles post-processing, and a 1e6-star ModelFit batch: fast == plain formulation."""
     from mcmc_dynamics_amd import DataReader, synthetic

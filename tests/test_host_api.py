@@ -210,6 +210,49 @@ def test_chain_statistics():
     assert pars["ra_center"].shape == (20 * 50,) and np.all(pars["ra_center"] == 56.345)
 
 
+def test_chain_statistics_match_the_reference():
+    """Runner.compute_percentiles / compute_bestfit_values / convert_to_parameters (runner.py:521-660),
+    get_amplitude_and_angle (utils/coordinates/get_amplitude_and_angle.py:10-51) and ConstantFit.compute_theta_vmax
+    (constant.py:156-214) against outputs of the reference for a fixed synthetic chain (tests/golden/chain_stats.npz,
+    generated by oracle/make_golden.py round2): a burn-in to discard, a rotation axis scattering around +-pi (wrap), an
+    axis in the first quadrant, and theta_0 given in place of v_maxx."""
+    from mcmc_dynamics_amd.utils.coordinates import get_amplitude_and_angle
+    g = load_golden("chain_stats")
+    cf = ConstantFit(DataReader({k: g[k] for k in ("ra", "dec", "v", "verr")}))
+    cf.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+    cf.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+    names = [str(n) for n in g["names"]]
+    assert cf.fitted_parameters == names and list(cf.parameters) == [str(n) for n in g["all_names"]]
+    chain, n_burn = g["chain"], int(g["n_burn"])
+    assert np.array_equal(cf.compute_percentiles(chain, n_burn=n_burn), g["percentiles_default"])
+    assert np.array_equal(cf.compute_percentiles(chain, n_burn=n_burn, pct=[2.5, 97.5]), g["percentiles_custom"])
+    best = cf.compute_bestfit_values(chain, n_burn=n_burn)
+    rows = np.array([[best.loc[r][n] for n in names] for r in ("median", "uperr", "loerr")])
+    assert np.array_equal(rows, g["bestfit"])
+    # as in the reference, the medians are written back into the parameters (runner.py:649)
+    assert np.array_equal([cf.parameters[n].value for n in names], g["parameters_after_bestfit"])
+    pars = cf.convert_to_parameters(chain, n_burn=n_burn)
+    assert np.array_equal(np.stack([pars[str(n)] for n in g["all_names"]]), g["converted"])
+
+    def table(res):
+        return np.array([[res.loc[r][c] for c in ("v_max", "theta_0")] for r in ("median", "uperr", "loerr")])
+    res, v_max, theta = get_amplitude_and_angle(pars, return_samples=True)
+    np.testing.assert_allclose(table(res), g["amp_angle"], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(v_max, g["v_max_samples"], rtol=1e-14)
+    np.testing.assert_allclose(theta, g["theta_samples"], rtol=1e-14, atol=1e-15)
+    assert abs(abs(res.loc["median"]["theta_0"]) - np.pi) < 0.3 and np.ptp(theta) < np.pi      # the wrap was exercised
+    np.testing.assert_allclose(table(cf.compute_theta_vmax(chain, n_burn=n_burn)), g["theta_vmax_method"], rtol=1e-14, atol=1e-15)
+    pars_b = cf.convert_to_parameters(g["chain_b"], n_burn=0)
+    res_b, v_max_b, theta_b = get_amplitude_and_angle(pars_b, return_samples=True)
+    np.testing.assert_allclose(table(res_b), g["amp_angle_b"], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(v_max_b, g["v_max_samples_b"], rtol=1e-14)
+    alt = {"theta_0": np.arctan2(pars_b["v_maxy"], pars_b["v_maxx"]), "v_maxy": pars_b["v_maxy"]}
+    res_c, v_max_c, theta_c = get_amplitude_and_angle(alt, return_samples=True)
+    np.testing.assert_allclose(table(res_c), g["amp_angle_c"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(v_max_c, g["v_max_samples_c"], rtol=1e-13)
+    np.testing.assert_allclose(theta_c, g["theta_samples_c"], rtol=1e-13, atol=1e-15)
+
+
 def test_checkpoint_format(tmp_path):
     """{prefix}_chain.pkl holds (W, steps, P), {prefix}_lnprob.pkl holds (W, steps) (runner.py:458-477);
     read_final_chain returns chain[:, -1, :] for restarts (runner.py:499-519)."""

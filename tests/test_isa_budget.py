@@ -14,9 +14,9 @@ BUDGET = {                                   # VALU instructions per star-walker
     "CONST fixed centre": 8.6,
     "CONST free centre": 29.5,
     "BGFIXED fixed centre": 34.0,
-    "BGFIXED fixed, narrow": 26.5,
+    "BGFIXED fixed, narrow": 23.6,
     "BGGAUSS fixed centre": 54.0,
-    "BGGAUSS fixed, narrow": 49.0,
+    "BGGAUSS fixed, narrow": 45.1,
     "PROFILE fixed centre": 25.5,
 }
 

@@ -16,6 +16,7 @@ CASES = [
     ("model_fit_fixed", 3, False), ("model_fit_free", 3, True),                 # ModelFit (analysis/model.py)
     ("model_fit_gb_fixed", 4, False), ("model_fit_gb_free", 4, True),           # ModelFitGB
     ("model_fit_cb_fixed", 5, False), ("model_fit_cb_free", 5, True),           # ModelFitConstantBackground
+    ("model_fit_bg_gaussian_fixed", 6, False), ("model_fit_bg_gaussian_free", 6, True),   # ModelFit(background=Gaussian)
 ]
 
 
@@ -25,7 +26,7 @@ CASES = [
 def test_host_compiled_kernel_math_matches_reference(name, model, free, fast, chunk_len):
     g = load_golden(name)
     cat = {k: g[k] for k in ("ra", "dec", "v", "verr")}
-    if model == 1:
+    if model in (1, 6):
         cat["lnlike_bg"], cat["pmember"] = g["lnlike_background"], g["pmember"]
     if model in (2, 4, 5):
         cat["density"] = g["density"]
@@ -54,6 +55,18 @@ def test_per_star_outputs():
         assert np.max(np.abs(got - g["lnlike_no_sum"]) / np.abs(g["lnlike_no_sum"])) < 1e-12
         mem = emul.per_star(cat, row, 5, centre_of(g), 0)
         assert np.all((mem >= 0) & (mem <= 1))
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit_gb_membership_golden(which):
+    """ModelFitGB.calculate_membership_probabilities (model.py:458-510): the per-star kernel arithmetic at the chain's
+    median row against the reference's output."""
+    g = load_golden("model_fit_gb_membership_" + which)
+    cat = {k: g[k] for k in ("ra", "dec", "v", "verr", "density")}
+    centre = None if which == "free" else (float(g["ra_center"]), float(g["dec_center"]))
+    row = emul.abi_columns(g["names"], g["median"][None, :], 4, which == "free")[0]
+    got = emul.per_star(cat, row, 4, centre, 0)
+    assert np.max(np.abs(got - g["membership"])) < 1e-12
 
 
 def test_fast_paths_survive_outliers_and_extreme_backgrounds():

@@ -175,6 +175,38 @@ def test_model_fit_family(which):
     assert np.max(np.abs(per_star - g["lnlike_no_sum"]) / np.abs(g["lnlike_no_sum"])) < RTOL
 
 
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit_with_fixed_background(which):
+    """ModelFit(background=Gaussian): ModelFit.lnlike ends in Runner._calculate_lnlike (model.py:222 -> runner.py:272-286),
+    so the pmember mixture applies to the profile models as well (round-2 fixture from the reference)."""
+    g = load_golden("model_fit_bg_gaussian_" + which)
+    ok = np.isfinite(g["lnprob"])
+    lnbg = oracle.gaussian_background(g["v"], g["verr"], float(g["bg_mean"]), float(g["bg_sigma"]))
+    assert np.max(np.abs(lnbg - g["lnlike_background"])) < 1e-12
+    got = np.array([oracle.faithful_model_lnlike(_cat(g), lnlike_background=lnbg, prior=g["pmember"],
+                                                 **{k: _named(g, r, which)[k] for k in CORE}) for r in g["values"][ok]])
+    assert rel_err(got, g["lnprob"][ok]) < RTOL and (~ok).sum() == 1
+    assert np.array_equal(np.isfinite(g["lnprior"]), ok)
+
+
+@pytest.mark.parametrize("which", ["fixed", "free"])
+def test_model_fit_gb_membership_matches_reference(which):
+    """ModelFitGB.calculate_membership_probabilities (model.py:458-510) at the chain's medians."""
+    g = load_golden("model_fit_gb_membership_" + which)
+    chain, n_burn = g["chain"], int(g["n_burn"])
+    med = np.percentile(chain[:, n_burn:, :].reshape(-1, chain.shape[2]), 50, axis=0)
+    assert np.array_equal(med, g["median"])
+    p = _named(g, med, which)
+    cat = _cat(g, ("density",))
+    v_los = oracle.model_rotation(cat["ra"], cat["dec"], p["v_sys"], p["v_maxx"], p["v_maxy"], p["r_peak"], p["ra_center"], p["dec_center"])
+    sig = oracle.model_dispersion(cat["ra"], cat["dec"], p["sigma_max"], p["a"], p["ra_center"], p["dec_center"])
+    norm = cat["verr"] ** 2 + sig ** 2
+    lc = -0.5 * np.log(2 * np.pi * norm) - 0.5 * (cat["v"] - v_los) ** 2 / norm
+    lb = oracle.gaussian_background(cat["v"], cat["verr"], p["v_back"], p["sigma_back"])
+    got = oracle.model_membership(cat, lc, lb, cat["density"] / (cat["density"] + p["f_back"]))
+    assert np.max(np.abs(got - g["membership"])) < 1e-13
+
+
 def test_single_stars_background_matches_reference():
     """oracle.single_stars_background against background.SingleStars of the reference (single_stars.py:42-77):
     sigma_int = 0 and 2.5 km/s, a > 1e4-sigma outlier, a test star exactly on a comparison star, and M = 1."""
