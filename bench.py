@@ -316,8 +316,10 @@ def timed_steps(gpu_cat, group, steps, warmup, ramp_seconds, stride):
             gpu_cat.enqueue()
     for _ in range(warmup):
         gpu_cat.enqueue()
+    # drop the ramp / warm-up event pairs WITHOUT reading them: reading hundreds of pairs takes milliseconds, and a GPU
+    # that idles for ~10 ms leaves its sustained clocks (tools/k20_probe.py: 236 instead of 208 us per step at K = 20)
+    gpu_cat.set_option("timing_discard", 1)
     barrier()
-    gpu_cat.timing_collect()                         # drop ramp and warm-up launches
     t0 = time.perf_counter()
     for _ in range(steps):
         gpu_cat.enqueue()

@@ -184,6 +184,8 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *                      event pair per main-kernel launch for mcd_timing_collect
  *   "timing_stride" n: with "timing" = 2, record the event pair on every n-th launch only (default 1); the events cost a
  *                      signal packet each between back-to-back kernels, so a throughput harness samples
+ *   "timing_discard" (any value): drop the event pairs recorded so far without reading them -- cheap, unlike
+ *                      mcd_timing_collect, whose hipEventElapsedTime calls idle the GPU for milliseconds
  *   "timing_reserve" n: create the event pairs for n launches of "timing" = 2 now, so that a measured loop does not
  *                      pay for hipEventCreate
  *   "fast_path"     0: always use the plain per-term log/divide kernels; 1 (default): the fast formulations
@@ -193,6 +195,8 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *   "zero_copy"     1 (default): on a single device mcd_loglike_batch lets the kernels read the parameter table
  *                      from / write the results to pinned mapped host memory instead of issuing H2D / D2H copies
  *   "target_waves"  number of waves the chunking aims for per device (default 12288)
+ *   "chunk_len"     explicit nominal chunk length in stars (rounded up to a multiple of 32; 0, the default: derived from
+ *                      "target_waves"); tuning aid
  *   "tail_split"    chunk schedule: 0 equal-length chunks; 1 (default): the last ~15 % of a large parameter set is
  *                      cut into half- and quarter-length chunks so that the launch ends on short waves; 2-4:
  *                      other guided schedules kept for tuning (see build_workset in mcd_api.hip)

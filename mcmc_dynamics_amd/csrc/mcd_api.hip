@@ -172,6 +172,7 @@ struct mcd_catalog {
     int64_t timing_launches = 0;
     int tail_split = 1;                // guided chunk schedule (shorter chunks at the end of a launch)
     int64_t target_waves = 12288;
+    int64_t chunk_len = 0;             // option "chunk_len": explicit nominal chunk length (0: from target_waves)
     // state of the last evaluation
     int64_t cur_walkers = 0;
     double last_kernel_ms = -1.0, last_device_ms = -1.0;
@@ -223,7 +224,7 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     MCD_HIP(hipSetDevice(slot.device));
 
     const mcd::ChunkPlan plan = mcd::plan_chunks(cat->bin_offsets, sh.star_begin, sh.n, n_walkers, cat->target_waves,
-                                                 cat->tail_split, cat->stats.narrow_exceptions);
+                                                 cat->tail_split, cat->stats.narrow_exceptions, cat->chunk_len);
     const std::vector<mcd::Chunk>& chunks = plan.chunks;
     const std::vector<int64_t>& offs = plan.offsets;
     const std::vector<uint8_t>& general = plan.general;
@@ -903,6 +904,15 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         for (Shard& sh : cat->shards) sh.ring_used = 0;
         return MCD_OK;
     }
+    if (!std::strcmp(key, "timing_discard")) {
+        // forget the event pairs recorded so far without reading them (hipEventElapsedTime over hundreds of pairs takes
+        // milliseconds, long enough for an idle GPU to leave its sustained clocks right before a measured region)
+        int rc = sync_all(cat);
+        if (rc != MCD_OK) return rc;
+        for (Shard& sh : cat->shards) sh.ring_used = 0;
+        cat->timing_launches = 0;
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "timing_stride")) {
         if (value < 1) return fail(MCD_ERR_INVALID, "timing_stride must be >= 1");
         int rc = sync_all(cat);
@@ -931,12 +941,14 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     if (!std::strcmp(key, "zero_copy")) { cat->zero_copy = value != 0; return MCD_OK; }
-    if (!std::strcmp(key, "tail_split") || !std::strcmp(key, "target_waves")) {
-        const bool is_split = key[1] == 'a' && key[0] == 't' && key[2] == 'i';
-        if (!is_split && value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");
+    if (!std::strcmp(key, "tail_split") || !std::strcmp(key, "target_waves") || !std::strcmp(key, "chunk_len")) {
+        const bool is_split = !std::strcmp(key, "tail_split"), is_len = !std::strcmp(key, "chunk_len");
+        if (!is_split && !is_len && value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");
+        if (is_len && value < 0) return fail(MCD_ERR_INVALID, "chunk_len must be >= 0");
         int rc = sync_all(cat);
         if (rc != MCD_OK) return rc;
         if (is_split) cat->tail_split = (int)value;
+        else if (is_len) cat->chunk_len = value;
         else cat->target_waves = value;
         for (Shard& sh : cat->shards) {            // chunk tables depend on it: rebuild lazily
             (void)hipSetDevice(cat->ctx->slots[sh.slot].device);

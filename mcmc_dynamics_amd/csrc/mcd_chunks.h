@@ -44,20 +44,33 @@ struct ChunkPlan {
 // Chunk table of the shard [star_begin, star_begin + n) of a catalogue whose parameter sets (radial bins) are the
 // global star ranges bin_offsets[p] .. bin_offsets[p + 1]; a bin that straddles the shard edge contributes its local
 // part (the partial sums of the shards add up in the all-reduce).
-//   * nominal length = roundup32(n n_wtiles / target_waves), at least 64: `target_waves` waves per launch
+//   * nominal length = the odd multiple of 32 nearest to n n_wtiles / waves, at least 96, with waves = target_waves for
+//     >= 256 walkers (2/3 and 1/2 of it for 2-3 and 1 walker tiles)
 //   * guided schedule (tail_split): workgroups are dispatched in chunk order, so the end of a large parameter set is
 //     cut into shorter chunks and the launch ends on short waves.  0 equal chunks; 1 = 85/10/5 % at len, len/2, len/4;
 //     2 = 70/15/10/5 % down to len/8; 3, 4 = guided self-scheduling, chunk = remaining work / (G x resident waves)
 //   * every chunk length is a multiple of 8 except the last chunk of a parameter set
 //   * narrow_exceptions: ascending GLOBAL star indices (mcd_guard.h)
 inline ChunkPlan plan_chunks(const std::vector<int64_t>& bin_offsets, int64_t star_begin, int64_t n, int64_t n_walkers,
-                             int64_t target_waves, int tail_split, const std::vector<int64_t>& narrow_exceptions) {
+                             int64_t target_waves, int tail_split, const std::vector<int64_t>& narrow_exceptions,
+                             int64_t chunk_len = 0) {
     ChunkPlan plan;
     const int64_t n_psets = (int64_t)bin_offsets.size() - 1;
     const int64_t n_wtiles = (n_walkers + 63) / 64;
-    int64_t len = (n * n_wtiles + target_waves - 1) / std::max<int64_t>(1, target_waves);
-    len = std::max<int64_t>(64, (len + 31) / 32 * 32);          // quarter-length tail chunks stay multiples of 8
-    len = std::min(len, kMaxChunkLen);
+    // Fewer, longer chunks when a workgroup's four waves are spread over several chunks (<= 128 walkers): measured best
+    // near 12288 / 8192 / 6144 waves per launch for >= 4 / 2-3 / 1 walker tiles (tools/chunk_len_probe.py).
+    const int64_t waves = std::max<int64_t>(1, n_wtiles >= 4 ? target_waves : (n_wtiles >= 2 ? target_waves * 2 / 3 : target_waves / 2));
+    int64_t len = (n * n_wtiles + waves - 1) / waves;
+    if (chunk_len > 0) {
+        len = std::max<int64_t>(64, (chunk_len + 31) / 32 * 32);   // explicit nominal length (option "chunk_len", tuning)
+    } else {
+        // nearest ODD multiple of 32 (quarter-length tail chunks stay multiples of 8), at least 96: chunk strides that are
+        // multiples of 4 KiB (64 stars of 64-byte records, 128 stars of 32-byte records) put the scalar record loads of
+        // all resident waves on the same cache channels -- measured 15 - 35 % slower at 128, 256, 384, 512 stars per chunk
+        const int64_t k = std::max<int64_t>(1, len / 64);
+        len = 32 * (2 * k + 1);
+    }
+    len = std::min(len, kMaxChunkLen - 32);
     plan.len = len;
     plan.offsets.assign(n_psets + 1, 0);
     for (int64_t p = 0; p < n_psets; ++p) {

@@ -53,7 +53,7 @@ def test_chunk_tables_cover_every_shard_exactly_once(n_shards, n_walkers):
                 local = max(0, min(offs[s + 1], begin + cnt) - max(offs[s], begin))
                 assert c[o[s]:o[s + 1]].sum() == local
             assert plan["max_chunks_per_pset"] == (np.diff(o).max() if len(o) > 1 else 0)
-            assert plan["len"] % 32 == 0 and plan["len"] >= 64
+            assert plan["len"] % 64 == 32 and plan["len"] >= 96               # odd multiple of 32 (no 4 KiB chunk strides)
             if plan["uniform_len"]:
                 L = plan["uniform_len"]
                 assert len(offs) == 2 and np.array_equal(b, np.arange(len(b)) * L) and np.all(c[:-1] == L)
@@ -73,7 +73,12 @@ def test_guided_schedule_ends_on_short_chunks_and_equal_schedule_is_arithmetic()
     assert flat["uniform_len"] == 352 and len(flat["begin"]) == -(-1000000 // 352)
     # chunk length is capped so that per-chunk exponent sums stay inside int32
     huge = em.plan_chunks([0, 8 << 20], 0, 8 << 20, 64, 1, 0)
-    assert huge["len"] == 1 << 20 and huge["count"].max() == 1 << 20
+    assert huge["len"] == (1 << 20) - 32 and huge["count"].max() == (1 << 20) - 32
+    # fewer, longer chunks for <= 128 walkers; never a multiple of 64 stars
+    assert em.plan_chunks([0, 1000000], 0, 1000000, 128, 12288, 1)["len"] == 224
+    assert em.plan_chunks([0, 1000000], 0, 1000000, 64, 12288, 1)["len"] == 160
+    assert em.plan_chunks([0, 1250000], 0, 1250000, 256, 12288, 1)["len"] == 416
+    assert em.plan_chunks([0, 5000], 0, 5000, 256, 12288, 1)["len"] == 96
 
 
 @pytest.mark.parametrize("n_shards", [2, 3, 8])

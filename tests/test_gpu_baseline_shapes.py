@@ -1,0 +1,185 @@
+"""GPU: every BASELINE.json configuration at its EXACT shape, in the driver-run suite (the parity cases elsewhere use
+smaller catalogues):
+
+  C2  1e5 synthetic stars x 256 walkers, rotation+dispersion, f64 -- all 256 walkers against the oracle
+  C3  1e6 x 256 with the fixed-Gaussian-background mixture -- tests/test_gpu_kernels.py::test_full_size_c3_properties
+  C4  1e7 stars in 8 shards on one GPU -- tests/test_gpu_kernels.py::test_c4_size_shards
+  C5  1e6 stars, make_radial_bins(nstars=1000, dlogr=0.05) (utils/files/data_reader.py:71-140; bin/run_tests.py:75-124),
+      512 walkers per bin, f64 / f32 terms + f64 accumulation / f32
+
+plus the combination the XCD-grouped launch path serves: a binned catalogue with more than 256 walkers and several
+parameter sets, for the mixture models as well."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+NAMES4 = ["v_sys", "sigma_max", "v_maxx", "v_maxy"]
+
+
+@pytest.fixture(scope="module")
+def native():
+    from mcmc_dynamics_amd import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def ctx(native):
+    return native.default_context()
+
+
+def _catalog(n, config, background=False, min_sep_arcmin=1e-2):
+    """Synthetic catalogue of SURVEY 8(d); stars within `min_sep_arcmin` of the centre are moved (theta is ill-conditioned
+    there in the reference's own formula, see tests/test_gpu_kernels.py::_synthetic)."""
+    from mcmc_dynamics_amd import synthetic
+    from oracle import lnprob_numpy as oracle
+    c = synthetic.make_catalog(n, config=config, background=background)
+    centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
+    if min_sep_arcmin:
+        dx, dy = oracle.calc_xy_offset(c["ra"], c["dec"], *centre)
+        r = np.hypot(dx, dy)
+        near = r < min_sep_arcmin
+        if near.any():
+            donor = int(np.argmax(r))
+            c["ra"][near], c["dec"][near] = c["ra"][donor], c["dec"][donor]
+    return c, centre
+
+
+def _oracle_blocks(cat, pos, centre, block=32, **kw):
+    """oracle.batched_constant_lnlike over blocks of walkers (bounds the (W, N) temporaries at 1e5+ stars)."""
+    from oracle import lnprob_numpy as oracle
+    return np.concatenate([oracle.batched_constant_lnlike(cat, pos[i:i + block], *centre, **kw)
+                           for i in range(0, len(pos), block)])
+
+
+def test_c2_exact_shape_against_the_oracle(native, ctx):
+    """C2: 1e5 stars x 256 walkers, ConstantFit, fixed centre, float64 -- every walker against the NumPy oracle."""
+    from mcmc_dynamics_amd import synthetic
+    c, centre = _catalog(100000, 2)
+    pos = synthetic.make_walkers(256, NAMES4, c["truth"], config=2)
+    cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST, centre=centre)
+    got = cat.loglike(pos)
+    assert got.shape == (256,) and cat.fast_level == 1
+    want = _oracle_blocks(c, pos, centre)
+    assert rel_err(got, want) < RTOL
+    assert np.array_equal(cat.loglike(pos), got)                       # bitwise repeatable
+    cat.set_option("fast_path", 0)
+    assert rel_err(cat.loglike(pos), want) < RTOL                      # the plain kernels at the same shape
+    # the walker-halves an emcee stretch move evaluates (128 proposals per call) give the same numbers
+    cat.set_option("fast_path", 1)
+    assert rel_err(np.concatenate([cat.loglike(pos[:128]), cat.loglike(pos[128:])]), want) < RTOL
+
+
+@pytest.fixture(scope="module")
+def c5(native, ctx):
+    """C5 catalogue: 1e6 stars sorted into the reference's radial bins, 512 walkers."""
+    from mcmc_dynamics_amd import DataReader, synthetic
+    c, centre = _catalog(1000000, 5, min_sep_arcmin=0)
+    reader = DataReader({k: c[k] for k in ("ra", "dec", "v", "verr")})
+    reader.make_radial_bins(centre[0], centre[1], nstars=1000, dlogr=0.05)
+    srt, offs = reader.sorted_by_bin()
+    cols = {k: np.asarray(srt.data[k]) for k in ("ra", "dec", "v", "verr")}
+    pos = synthetic.make_walkers(512, NAMES4, c["truth"], config=5)
+    return cols, np.asarray(offs, dtype=np.int64), pos, centre
+
+
+def test_c5_exact_shape_f64(native, ctx, c5):
+    cols, offs, pos, centre = c5
+    n_bins = len(offs) - 1
+    assert offs[-1] == 1000000 and n_bins >= 20 and np.all(np.diff(offs) >= 1000)
+    params = np.ascontiguousarray(np.broadcast_to(pos, (n_bins,) + pos.shape))
+    binned = native.Catalog(ctx, cols["ra"], cols["dec"], cols["v"], cols["verr"], model=native.MODEL_CONST, centre=centre,
+                            bin_offsets=offs)
+    got = binned.loglike(params)
+    assert got.shape == (n_bins, 512) and np.all(np.isfinite(got))
+    assert np.array_equal(binned.loglike(params), got)                 # bitwise repeatable
+    # the same walkers in every bin: the sum over the bins is the un-binned log-likelihood (SURVEY 8(c) known answer 4)
+    flat = native.Catalog(ctx, cols["ra"], cols["dec"], cols["v"], cols["verr"], model=native.MODEL_CONST, centre=centre)
+    assert rel_err(got.sum(axis=0), flat.loglike(pos)) < RTOL
+    # two bins against the oracle on all 512 walkers (a middle bin and the last, largest one)
+    for b in (n_bins // 2, n_bins - 1):
+        sub = {k: v[offs[b]:offs[b + 1]] for k, v in cols.items()}
+        assert rel_err(got[b], _oracle_blocks(sub, pos, centre, block=16 if len(sub["v"]) > 200000 else 64)) < RTOL, b
+    # per-bin ensembles that differ from bin to bin: every bin still equals a stand-alone catalogue of its stars
+    rng = np.random.default_rng(5)
+    varied = params * (1.0 + 0.01 * rng.normal(size=(n_bins, 1, 4)))
+    varied[..., 1] = np.abs(varied[..., 1])
+    got_v = binned.loglike(varied)
+    for b in (0, 3, n_bins - 2):
+        sl = slice(offs[b], offs[b + 1])
+        one = native.Catalog(ctx, cols["ra"][sl], cols["dec"][sl], cols["v"][sl], cols["verr"][sl], model=native.MODEL_CONST,
+                             centre=centre)
+        assert rel_err(got_v[b], one.loglike(varied[b])) < RTOL, b
+        one.close()
+    binned.close()
+    flat.close()
+
+
+def test_c5_exact_shape_precision_sweep(native, ctx, c5):
+    """float32 vs float64 at the full C5 shape: f32 terms + f64 accumulation <= 1e-6, pure f32 <= 2e-5 relative per
+    (bin, walker) output (the tolerances of test_precision_sweep_c5; SURVEY appendix: 9.5e-9 / 1.8e-7 at 1e5 stars)."""
+    cols, offs, pos, centre = c5
+    n_bins = len(offs) - 1
+    params = np.ascontiguousarray(np.broadcast_to(pos, (n_bins,) + pos.shape))
+    out = {}
+    for prec in ("f64", "f32acc64", "f32"):
+        cat = native.Catalog(ctx, cols["ra"], cols["dec"], cols["v"], cols["verr"], model=native.MODEL_CONST, centre=centre,
+                             bin_offsets=offs, precision=prec)
+        out[prec] = cat.loglike(params)
+        cat.close()
+    assert rel_err(out["f32acc64"], out["f64"]) < 1e-6
+    assert rel_err(out["f32"], out["f64"]) < 2e-5
+    # and on the un-binned sum (1e6 terms per walker)
+    assert rel_err(out["f32acc64"].sum(axis=0), out["f64"].sum(axis=0)) < 1e-6
+    assert rel_err(out["f32"].sum(axis=0), out["f64"].sum(axis=0)) < 2e-5
+
+
+@pytest.mark.parametrize("n_walkers", [320, 512])
+@pytest.mark.parametrize("model", ["const", "bgfixed", "bggauss"])
+def test_binned_catalogue_with_more_than_256_walkers(native, ctx, model, n_walkers):
+    """Radial bins x W > 256: several workgroups per chunk (XCD-grouped launch) with several parameter sets, idle lanes in
+    the last walker tile (W = 320), mixture models included.  Every bin against the oracle, per-bin walker ensembles."""
+    from mcmc_dynamics_amd import synthetic
+    from oracle import lnprob_numpy as oracle
+    c, centre = _catalog(60000, 3, background=True)
+    dx, dy = oracle.calc_xy_offset(c["ra"], c["dec"], *centre)
+    bins = oracle.make_radial_bins(np.hypot(dx, dy), 4000, 0.1).astype(np.int64)
+    order = np.argsort(bins, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(bins))]).astype(np.int64)
+    n_bins = len(offs) - 1
+    assert n_bins >= 5
+    srt = {k: (v[order] if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    names = NAMES4 + (["v_back", "sigma_back", "f_back"] if model == "bggauss" else [])
+    base = synthetic.make_walkers(n_walkers, names, c["truth"], config=3)
+    rng = np.random.default_rng(n_walkers)
+    params = np.stack([base * (1.0 + 0.01 * rng.normal(size=base.shape)) for _ in range(n_bins)])
+    params[..., 1] = np.abs(params[..., 1])
+    if model == "bggauss":
+        params[..., 5] = np.abs(params[..., 5])
+        params[..., 6] = np.clip(params[..., 6], 0.01, 0.99)
+    lnbg = oracle.gaussian_background(srt["v"], srt["verr"], synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])
+    if model == "const":
+        kw, mid = {}, native.MODEL_CONST
+    elif model == "bgfixed":
+        kw, mid = dict(lnlike_bg=lnbg, pmember=srt["pmember"]), native.MODEL_CONST_BGFIXED
+    else:
+        kw, mid = dict(density=srt["density"]), native.MODEL_CONST_BGGAUSS
+    cat = native.Catalog(ctx, srt["ra"], srt["dec"], srt["v"], srt["verr"], model=mid, centre=centre, bin_offsets=offs, **kw)
+    for fast in (1, 0):
+        cat.set_option("fast_path", fast)
+        got = cat.loglike(params)
+        assert got.shape == (n_bins, n_walkers)
+        for b in range(n_bins):
+            sl = slice(offs[b], offs[b + 1])
+            sub = {k: v[sl] for k, v in srt.items() if isinstance(v, np.ndarray)}
+            if model == "const":
+                want = oracle.batched_constant_lnlike(sub, params[b], *centre)
+            elif model == "bgfixed":
+                want = oracle.batched_constant_lnlike(sub, params[b], *centre, lnlike_background=lnbg[sl], pmember=sub["pmember"])
+            else:
+                want = oracle.batched_constant_gb_lnlike(sub, params[b], *centre)
+            assert rel_err(got[b], want) < RTOL, (fast, b)
+    cat.close()
