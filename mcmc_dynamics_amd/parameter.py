@@ -47,8 +47,57 @@ class ExpressionError(ValueError):
     """An ``initials`` / ``lnprior`` / ``expr`` string failed to parse or evaluate."""
 
 
+_ALLOWED_NODES = None
+
+
+def _allowed_nodes():
+    import ast
+    global _ALLOWED_NODES
+    if _ALLOWED_NODES is None:
+        names = ["Expression", "BinOp", "UnaryOp", "BoolOp", "Compare", "IfExp", "Call", "keyword", "Name", "Load", "Constant",
+                 "Attribute", "Subscript", "Slice", "Tuple", "List",
+                 "Add", "Sub", "Mult", "Div", "FloorDiv", "Mod", "Pow", "USub", "UAdd", "Not", "And", "Or",
+                 "Eq", "NotEq", "Lt", "LtE", "Gt", "GtE", "Index"]
+        _ALLOWED_NODES = tuple(getattr(ast, n) for n in names if hasattr(ast, n))
+    return _ALLOWED_NODES
+
+
+def check_expression(text):
+    """Parse ``text`` and accept only plain arithmetic: numbers, names, arithmetic / comparison / boolean operators,
+    conditional expressions, indexing, tuples / lists, calls and attribute access without leading underscores.  The
+    reference evaluates these strings with asteval, which refuses dunder attributes and has no ``import`` / ``lambda`` /
+    comprehension escape routes into the interpreter; ``eval`` with an empty ``__builtins__`` alone is not a sandbox
+    (``().__class__.__base__.__subclasses__()`` reaches ``subprocess.Popen``), so the tree is validated before it is
+    compiled.  Returns the parsed ``ast.Expression``."""
+    import ast
+    try:
+        tree = ast.parse(text.strip(), "<parameter expression>", "eval")
+    except SyntaxError as exc:
+        raise ExpressionError("cannot parse expression '{0}': {1}".format(text, exc))
+    allowed = _allowed_nodes()
+    for node in ast.walk(tree):
+        if not isinstance(node, allowed):
+            raise ExpressionError("'{0}' is not allowed in a parameter expression: '{1}'".format(type(node).__name__, text))
+        if isinstance(node, ast.Attribute) and node.attr.startswith("_"):
+            raise ExpressionError("attribute '{0}' is not allowed in a parameter expression: '{1}'".format(node.attr, text))
+        if isinstance(node, ast.Name) and node.id.startswith("_"):
+            raise ExpressionError("name '{0}' is not allowed in a parameter expression: '{1}'".format(node.id, text))
+        if isinstance(node, ast.Constant) and isinstance(node.value, (str, bytes)):
+            raise ExpressionError("string constants are not allowed in a parameter expression: '{0}'".format(text))
+        if isinstance(node, ast.Call):
+            root = node.func
+            while isinstance(root, ast.Attribute):
+                root = root.value
+            if not isinstance(root, ast.Name):                      # e.g. (lambda: ...)(), f()(), [..][0]()
+                raise ExpressionError("only named functions can be called in a parameter expression: '{0}'".format(text))
+    return tree
+
+
 class _Evaluator(object):
-    """Symbol table + evaluation of the small Python expressions found in parameter files."""
+    """Symbol table + evaluation of the small Python expressions found in parameter files (``initials``, ``lnprior``,
+    ``expr``).  Expressions are validated by ``check_expression`` and may only call what the symbol table holds: the
+    NumPy functions of ``_expression_namespace``, ``rng`` (a ``numpy.random.Generator``), scipy's ``uniform`` / ``norm`` /
+    ``lognorm`` and user symbols -- the set the reference registers with asteval (parameter.py:17-21, 73-74)."""
 
     def __init__(self, rng_seed=None, usersyms=None):
         self._base = _expression_namespace()
@@ -62,16 +111,16 @@ class _Evaluator(object):
         return set(k for k in self.symtable if k not in self._base)
 
     def compile(self, text):
-        try:
-            return compile(text.strip(), "<parameter expression>", "eval")
-        except SyntaxError as exc:
-            raise ExpressionError("cannot parse expression '{0}': {1}".format(text, exc))
+        tree = check_expression(text)
+        return compile(tree, "<parameter expression>", "eval")
 
     def __call__(self, code, **local):
         if isinstance(code, str):
             code = self.compile(code)
         try:
             return eval(code, {"__builtins__": {}}, dict(self.symtable, **local))
+        except ExpressionError:
+            raise
         except Exception as exc:
             raise ExpressionError("cannot evaluate expression: {0}".format(exc))
 

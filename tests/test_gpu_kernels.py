@@ -141,7 +141,24 @@ def test_abi_errors(native, ctx):
             fresh.set_option(key, bad)
     with pytest.raises(native.NativeError):
         fresh.membership(g["values"][0])                 # membership needs a background model
-    assert np.all(np.isfinite(fresh.loglike(g["values"][np.isfinite(g["lnprior"])])))   # still usable afterwards
+    ok_rows = g["values"][np.isfinite(g["lnprior"])]
+    assert np.all(np.isfinite(fresh.loglike(ok_rows)))   # still usable afterwards
+    # a failed upload leaves NOTHING staged: enqueue / fetch answer with a status, they must not touch evicted buffers
+    # (more than 8 walker counts evict the cache of work buffers; the 10th upload then fails on its column count)
+    import ctypes
+    for w in range(1, 10):
+        fresh.loglike(ok_rows[:w])
+    bad = np.zeros((3, 5))
+    rc = fresh.lib.mcd_params_upload(fresh.handle, 3, 5, bad.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    assert rc == -1 and b"columns" in fresh.lib.mcd_last_error()
+    with pytest.raises(native.NativeError, match="staged"):
+        fresh.enqueue()
+    with pytest.raises(native.NativeError, match="evaluated|staged"):
+        fresh.fetch()
+    assert np.array_equal(fresh.loglike(ok_rows[:4]), fresh.loglike(ok_rows)[:4])       # and it recovers
+    fresh.set_option("chunk_len", 100)                   # tuning option: rounded up to 128, results unchanged to rounding
+    assert rel_err(fresh.loglike(ok_rows), native.Catalog(ctx, g["ra"], g["dec"], g["v"], g["verr"], model=native.MODEL_CONST,
+                                                          centre=(float(g["ra_center"]), float(g["dec_center"]))).loglike(ok_rows)) < 1e-13
     fresh.close()
     with pytest.raises(native.NativeError):
         fresh.loglike(g["values"])                       # closed catalogue

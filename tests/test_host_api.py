@@ -106,6 +106,37 @@ def test_bounds_are_inclusive_and_checked_for_fixed_parameters():
         Parameters().add("not a name", value=1.0)
 
 
+def test_expressions_cannot_reach_the_interpreter():
+    """`initials` / `lnprior` / `expr` strings come from parameter files; the reference evaluates them with asteval, which
+    blocks dunder attributes, lambdas, comprehensions and imports.  The same escapes must fail here -- at parse time, before
+    anything is evaluated -- while the expressions the reference's configs and scripts use keep working."""
+    from mcmc_dynamics_amd.parameter import ExpressionError
+    pars = ConstantFit.default_parameters()
+    escape = "[c for c in ().__class__.__base__.__subclasses__() if c.__name__=='Popen']"
+    for bad in (escape, "().__class__", "rng.__class__.__mro__", "(lambda: 1)()", "__import__('os').system('true')",
+                "getattr(rng, 'bit_generator')", "rng._bit_generator", "norm.__init__.__globals__", "f'{n}'",
+                "rng.normal(size=n).__array_interface__", "{1: 2}", "[x for x in (1, 2)]", "open('/etc/passwd')"):
+        with pytest.raises(ExpressionError):
+            pars["v_sys"].initials = bad
+            pars["v_sys"].evaluate_initials(4)
+        with pytest.raises(ExpressionError):
+            pars["v_sys"].lnprior = bad
+            pars["v_sys"].evaluate_lnprior(0.5)
+    # what the reference's parameter files and scripts contain (config/*.json, bin/run.py:490, bin/run_test_5139_*.py)
+    pars = ConstantFit.default_parameters()
+    pars["sigma_max"].set(value=7.0)
+    for good, par in (("rng.lognormal(mean=2.30, sigma=0.5, size=n)", "sigma_max"), ("rng.normal(loc=0, scale=2, size=n)", "v_maxx"),
+                      ("300*rng.beta(a=2, b=5, size=n)", "v_maxy"), ("rng.uniform(-0.5, 0.5, size=n)", "v_sys"),
+                      ("sigma_max*rng.lognormal(size=n)", "v_sys")):
+        pars[par].initials = good
+        out = pars[par].evaluate_initials(5)
+        assert out.shape == (5,) and np.all(np.isfinite(out))
+    pars["v_sys"].lnprior = "norm.logpdf(val, loc=1.0, scale=2.0)"
+    assert pars["v_sys"].evaluate_lnprior(0.5) == pytest.approx(-1.643335713764618)
+    pars["v_sys"].lnprior = "0.0 if -5 <= val <= 5 else -inf"
+    assert pars["v_sys"].evaluate_lnprior(9.0) == -np.inf
+
+
 def test_unit_handling():
     p = Parameter("a", value=30.0, unit="arcsec", min=0.0)
 

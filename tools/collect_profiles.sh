@@ -1,0 +1,20 @@
+#!/bin/bash
+# Copy the summaries of a tools/final_sweep.sh run from gpurun_out/ into profiles/ (tracked).
+#     bash tools/collect_profiles.sh TAG ROUND      e.g.  bash tools/collect_profiles.sh r02a r02
+set -e
+TAG=$1
+R=$2
+O=gpurun_out
+P=profiles
+last() { tail -1 "$1"; }
+for w in c3 c2 c3gb c3const c4 m1 c3_k20 c5_f64 c5_f32acc64 c5_f32; do
+    last $O/bench_${TAG}_$w.json | python -m json.tool > $P/${R}_bench_$w.json
+done
+cp $O/kde_probe_$TAG.json $P/${R}_kde_probe.json
+python tools/summarize_rocprof.py stats $O/prof_${TAG}_c3 $P/${R}_c3_kernel_stats.txt > /dev/null
+python tools/summarize_rocprof.py stats $O/prof_${TAG}_c2 $P/${R}_c2_kernel_stats.txt > /dev/null
+cp "$(ls -t $O/prof_${TAG}_c3/*/*kernel_stats.csv | head -1)" $P/${R}_c3_kernel_stats.csv
+cp "$(ls -t $O/prof_${TAG}_c2/*/*kernel_stats.csv | head -1)" $P/${R}_c2_kernel_stats.csv
+python tools/summarize_rocprof.py pmc c3 $O/pmc_fetch_$TAG $O/pmc_write_$TAG $P/pmc_traffic.json loglike_kernel 64000000 > /dev/null
+python tools/summarize_rocprof.py sq $P/${R}_c3_sq_counters.json loglike_kernel 256000000 $O/sq_${TAG}_pass1 $O/sq_${TAG}_pass2 $O/sq_${TAG}_pass3 > /dev/null
+echo "profiles/${R}_* refreshed from sweep $TAG"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Measurement sweep on the GPU box (repo root): GPU tests, smoke, every bench workload, rocprofv3 kernel statistics of
-# C3 and C2, and the two PMC passes for roofline.traffic.  Everything lands under gpurun_out/; summaries are then
-# copied into profiles/ by tools/summarize_rocprof.py (see profiles/README.md).
+# C3 and C2, the two PMC passes for roofline.traffic and the three SQ-counter passes.  Everything lands under
+# gpurun_out/; tools/collect_profiles.sh then copies the summaries into profiles/ (see profiles/README.md).
 #     /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/final_sweep.sh TAG'
 set -o pipefail
 TAG=${1:-sweep}
@@ -13,18 +13,29 @@ tail -1 $O/gpu_tests_$TAG.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$TAG.log 2>&1 || { tail -20 $O/smoke_$TAG.log; exit 1; }
 tail -1 $O/smoke_$TAG.log
 for w in c3 c2 c3gb c3const c4 m1; do
-    timeout -k 10 300 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err || { tail -5 $O/bench_$w.err; exit 1; }
+    timeout -k 10 300 python bench.py --workload $w > $O/bench_${TAG}_$w.json 2> $O/bench_${TAG}_$w.err || { tail -5 $O/bench_${TAG}_$w.err; exit 1; }
     echo "bench $w done"
 done
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_c3_k20.json 2> $O/bench_${TAG}_c3_k20.err || exit 1
 for p in f64 f32acc64 f32; do
-    timeout -k 10 300 python bench.py --workload c5 --precision $p > $O/bench_c5_$p.json 2> $O/bench_c5_$p.err || exit 1
+    timeout -k 10 300 python bench.py --workload c5 --precision $p > $O/bench_${TAG}_c5_$p.json 2> $O/bench_${TAG}_c5_$p.err || exit 1
 done
 timeout -k 10 200 python tests/probes/kde_probe.py > $O/kde_probe_$TAG.json 2> $O/kde_probe.err || exit 1
 echo "benches done"
 rm -rf $O/prof_${TAG}_c3 $O/prof_${TAG}_c2 $O/pmc_fetch_$TAG $O/pmc_write_$TAG
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c3 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c3.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c3 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/prof_bench_${TAG}_c3.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c2 -- python3 bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c2.log 2>&1 || exit 1
 echo "kernel traces done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc > $O/pmc_fetch_$TAG.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc > $O/pmc_write_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/pmc_fetch_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/pmc_write_$TAG.log 2>&1 || exit 1
+echo "traffic passes done"
+A="SQ_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES"
+B="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS"
+C="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT"
+i=0
+for set in "$A" "$B" "$C"; do
+    i=$((i+1))
+    rm -rf $O/sq_${TAG}_pass$i
+    timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/sq_${TAG}_pass$i -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/sq_${TAG}_pass$i.log 2>&1 || { tail -5 $O/sq_${TAG}_pass$i.log; exit 1; }
+done
 echo "sweep $TAG complete"
