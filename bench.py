@@ -301,7 +301,10 @@ def timed_steps(gpu_cat, group, steps, warmup, ramp_seconds, stride):
     cold_ms, cold_n = gpu_cat.timing_collect()
     gpu_cat.set_option("timing_stride", stride)
     # Clock ramp (untimed, before the W warm-up steps): the GPU needs some 100 ms of load to reach its sustained clocks.
-    # Every rank runs the same number of launches (the all-reduce is collective).
+    # Every rank runs the same number of launches (the all-reduce is collective).  No HIP events in the ramp and the
+    # warm-up: hundreds of recorded-but-unread event pairs make the FIRST launch after the next synchronisation cost
+    # ~250 us of host time (the runtime retires them then) -- inside a K = 20 timed region that is 12 us per step.
+    gpu_cat.set_option("timing", 0)
     ramp_steps = 0
     if ramp_seconds > 0:
         t_r = time.perf_counter()
@@ -314,17 +317,31 @@ def timed_steps(gpu_cat, group, steps, warmup, ramp_seconds, stride):
             ramp_steps = int(group.allreduce(np.array([ramp_steps], dtype=np.int64), op="max")[0])
         for _ in range(ramp_steps):
             gpu_cat.enqueue()
-    for _ in range(warmup):
-        gpu_cat.enqueue()
-    # drop the ramp / warm-up event pairs WITHOUT reading them: reading hundreds of pairs takes milliseconds, and a GPU
-    # that idles for ~10 ms leaves its sustained clocks (tools/k20_probe.py: 236 instead of 208 us per step at K = 20)
-    gpu_cat.set_option("timing_discard", 1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    # The W warm-up steps; the last one runs alone behind a synchronisation: the first launch after a sync retires the
+    # runtime's backlog of completed commands (~100 us of host time after the ramp's thousands of launches), which
+    # would otherwise delay the first step of the timed region.
+    for _ in range(max(0, warmup - 1)):
         gpu_cat.enqueue()
     gpu_cat.sync()
+    if warmup > 0:
+        gpu_cat.enqueue()
+    gpu_cat.set_option("timing", 2)                  # (synchronises; the event pairs were created by timing_reserve)
+    barrier()
+    t0 = time.perf_counter()
+    if os.environ.get("MCD_BENCH_DEBUG"):
+        marks = []
+        for _ in range(steps):
+            gpu_cat.enqueue()
+            marks.append(time.perf_counter())
+        sys.stderr.write("enqueue call times (us): " + " ".join("{0:.0f}".format((b - a) * 1e6) for a, b in zip([t0] + marks[:-1], marks)) + "\n")
+    else:
+        for _ in range(steps):
+            gpu_cat.enqueue()
+    t_enq = time.perf_counter() - t0
+    gpu_cat.sync()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("MCD_BENCH_DEBUG"):
+        sys.stderr.write("timed region: enqueue loop {0:.1f} us, total {1:.1f} us, {2} steps\n".format(t_enq * 1e6, elapsed * 1e6, steps))
     if group is not None:
         group.barrier()
         elapsed = float(group.allreduce(np.array([elapsed]), op="max")[0])

@@ -46,7 +46,7 @@ typedef enum {
     MCD_ERR_HIP = -2,       /* a HIP runtime call failed (message has the call)     */
     MCD_ERR_RCCL = -3,      /* an RCCL call failed                                  */
     MCD_ERR_NO_DEVICE = -4, /* no usable gfx950 device                              */
-    MCD_ERR_NONFINITE = -5  /* reserved: non-finite input detected at upload        */
+    MCD_ERR_NONFINITE = -5  /* a NaN log-likelihood inside mcd_stretch_move         */
 } mcd_status;
 
 /* which per-star likelihood the catalogue is evaluated with */
@@ -171,6 +171,37 @@ int mcd_loglike_per_star(mcd_catalog* cat, int32_t k, const double* params, doub
 int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t n, const double* v,
                        const double* verr, double sigma_int, double* out, double* kernel_ms);
 
+/* ---- sampler support ---------------------------------------------------------------------- */
+
+/* One block of affine-invariant stretch-move steps with the per-half-step host loop inside the library: proposals from
+ * the complementary half of the ensemble, box prior, ONE mcd_loglike_batch of n_walkers / 2 rows, accept / reject.
+ * Replaces the Python loop around `Runner.lnprob` that emcee's EnsembleSampler runs for the reference
+ * (analysis/runner.py:403-419; prior: runner.py:182-217, parameter.py:684-705) when the prior is a box, as in the shipped
+ * parameter files.  All random numbers are the caller's, in the layout of mcmc_dynamics_amd/sampler.py:
+ *   order [n_steps][W]       permutation of 0..W-1 per step: first half = order[:W/2], second = order[W/2:]
+ *   zz    [n_steps][2][W/2]  stretch factors z ~ g(z), thr [n_steps][2][W/2] = log(u) - (n_dim - 1) log(z)
+ *   pick  [n_steps][2][W/2]  partner index into the complementary half
+ * pos [W][n_dim] and lnp [W] are updated in place; chain [n_steps][W][n_dim], lnprob_chain [n_steps][W] (either may be
+ * NULL) receive the state after every step; accepted [W] (may be NULL) is incremented.  The chain is bit-identical to the
+ * one the Python loop produces from the same numbers.  Un-binned catalogues only.  Returns MCD_ERR_NONFINITE when the
+ * likelihood produced a NaN (emcee raises "Probability function returned NaN"). */
+typedef struct {
+    int64_t n_walkers;          /* W, even */
+    int32_t n_dim;              /* free parameters (columns of pos) */
+    int32_t k;                  /* mcd_catalog_param_count(cat) */
+    const int32_t* col_source;  /* [k] index of the free parameter feeding kernel column j, or -1 for a constant column */
+    const double* col_const;    /* [k] value of a constant column (a fixed parameter), in the kernel's unit */
+    const double* col_factor;   /* [k] unit factor applied to a free-parameter column (1.0: none) */
+    const double* lo;           /* [n_dim] inclusive prior bounds; -inf / +inf where unbounded */
+    const double* hi;
+    int32_t fixed_ok;           /* 0: a fixed parameter violates its own bounds, every proposal is rejected (runner.py:207-214) */
+    int32_t reserved;
+} mcd_stretch_desc;
+
+int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* desc, int64_t n_steps, double* pos, double* lnp,
+                     const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
+                     double* lnprob_chain, int64_t* accepted);
+
 /* ---- introspection for the measurement harness ------------------------------------------- */
 
 const char* mcd_last_error(void);
@@ -194,6 +225,9 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *                      2: as 1 but never the narrow-range variant (testing aid)
  *   "zero_copy"     1 (default): on a single device mcd_loglike_batch lets the kernels read the parameter table
  *                      from / write the results to pinned mapped host memory instead of issuing H2D / D2H copies
+ *   "spin_us"       microseconds mcd_sync / fetch / batch poll the stream (hipStreamQuery) before they fall back to the
+ *                      blocking hipStreamSynchronize, whose interrupt wake-up adds 50 - 500 us of jitter to waits longer
+ *                      than a fraction of a millisecond (default 20000; 0: always block)
  *   "target_waves"  number of waves the chunking aims for per device (default 12288)
  *   "chunk_len"     explicit nominal chunk length in stars (rounded up to a multiple of 32; 0, the default: derived from
  *                      "target_waves"); tuning aid

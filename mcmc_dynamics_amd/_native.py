@@ -48,6 +48,9 @@ SYMBOLS = {
     "mcd_loglike_per_star": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_double_p, _c_double_p]),
     "mcd_kde_background": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int64, _c_double_p,
                                           _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
+    "mcd_stretch_move": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p,
+                                        ctypes.POINTER(ctypes.c_int32), _c_double_p, _c_double_p,
+                                        ctypes.POINTER(ctypes.c_int32), _c_double_p, _c_double_p, _c_int64_p]),
     "mcd_last_error": (ctypes.c_char_p, []),
     "mcd_abi_version": (ctypes.c_int, []),
     "mcd_last_kernel_ms": (ctypes.c_double, [ctypes.c_void_p]),
@@ -75,6 +78,15 @@ class CatalogDesc(ctypes.Structure):
         ("reserved", ctypes.c_int32),
         ("ra_center", ctypes.c_double), ("dec_center", ctypes.c_double),
         ("n_bins", ctypes.c_int64), ("bin_offsets", _c_int64_p),
+    ]
+
+
+class StretchDesc(ctypes.Structure):
+    """Mirror of ``mcd_stretch_desc``."""
+    _fields_ = [
+        ("n_walkers", ctypes.c_int64), ("n_dim", ctypes.c_int32), ("k", ctypes.c_int32),
+        ("col_source", ctypes.POINTER(ctypes.c_int32)), ("col_const", _c_double_p), ("col_factor", _c_double_p),
+        ("lo", _c_double_p), ("hi", _c_double_p), ("fixed_ok", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -323,6 +335,40 @@ class Catalog(object):
         out = np.empty(self.n_stars, dtype=np.float64)
         _check(self.lib, self.lib.mcd_loglike_per_star(self.handle, p.size, _ptr(p), _ptr(out)), "mcd_loglike_per_star")
         return out
+
+    def stretch_move(self, plan, pos, lnp, order, zz, thr, pick, chain=None, lnprob_chain=None, accepted=None):
+        """``mcd_stretch_move``: advance the ensemble by ``len(order)`` stretch-move steps with the half-step loop inside
+        the library.  ``plan``: dict with ``col_source`` (int32 [K]), ``col_const``, ``col_factor`` (float64 [K]), ``lo``,
+        ``hi`` (float64 [P]) and ``fixed_ok``.  ``pos`` (W, P) and ``lnp`` (W,) are C-contiguous float64 arrays updated
+        in place; random numbers as drawn by ``sampler.EnsembleSampler``."""
+        self._alive()
+        n_steps, w = order.shape
+        p = pos.shape[1]
+        for a, dt in ((pos, np.float64), (lnp, np.float64), (zz, np.float64), (thr, np.float64), (order, np.int32), (pick, np.int32)):
+            if a.dtype != dt or not a.flags.c_contiguous:
+                raise ValueError("stretch_move needs C-contiguous arrays of the documented dtypes")
+        if pos.shape != (w, p) or lnp.shape != (w,) or zz.shape != (n_steps, 2, w // 2) or thr.shape != zz.shape or pick.shape != zz.shape:
+            raise ValueError("stretch_move: inconsistent array shapes")
+        cols = [np.ascontiguousarray(plan["col_source"], dtype=np.int32), _f64(plan["col_const"]), _f64(plan["col_factor"]),
+                _f64(plan["lo"]), _f64(plan["hi"])]
+        if cols[0].size != self.k or cols[1].size != self.k or cols[2].size != self.k or cols[3].size != p or cols[4].size != p:
+            raise ValueError("stretch_move: plan does not match the catalogue / the number of free parameters")
+        d = StretchDesc()
+        d.n_walkers, d.n_dim, d.k = w, p, self.k
+        d.col_source = cols[0].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        d.col_const, d.col_factor, d.lo, d.hi = (_ptr(c) for c in cols[1:])
+        d.fixed_ok = 1 if plan.get("fixed_ok", True) else 0
+        for a, shape in ((chain, (n_steps, w, p)), (lnprob_chain, (n_steps, w))):
+            if a is not None and (a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape):
+                raise ValueError("stretch_move: chain buffers must be C-contiguous float64 of shape (steps, W, P) / (steps, W)")
+        if accepted is not None and (accepted.dtype != np.int64 or accepted.shape != (w,) or not accepted.flags.c_contiguous):
+            raise ValueError("stretch_move: accepted must be a C-contiguous int64 array of length W")
+        rc = self.lib.mcd_stretch_move(self.handle, ctypes.byref(d), n_steps, _ptr(pos), _ptr(lnp),
+                                       order.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(zz), _ptr(thr),
+                                       pick.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(chain), _ptr(lnprob_chain),
+                                       accepted.ctypes.data_as(_c_int64_p) if accepted is not None else None)
+        _check(self.lib, rc, "mcd_stretch_move")
+        self._walkers = w // 2
 
     def set_option(self, key, value):
         _check(self.lib, self.lib.mcd_set_option(self.handle, key.encode(), int(value)), "mcd_set_option")

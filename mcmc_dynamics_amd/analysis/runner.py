@@ -370,7 +370,46 @@ class Runner(object):
             return sampler
         except ImportError:
             from ..sampler import EnsembleSampler
-            return EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True, seed=seed)
+            return EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True, seed=seed,
+                                   block_fn=self._stretch_block if self._plan().simple and self.NATIVE_STRETCH else None)
+
+    NATIVE_STRETCH = True          # sub-classes whose posterior is not ONE un-binned catalogue switch this off
+
+    def _stretch_plan(self):
+        """Arguments of ``mcd_stretch_move`` for the current parameter configuration (box priors only: ``plan.simple``):
+        which free parameter feeds each kernel column, constants for fixed parameters, unit factors, bounds."""
+        plan = self._plan()
+        cached = getattr(self, "_stretch_cache", None)
+        if cached is not None and cached[0] is plan:
+            return cached[1]
+        free_pos = {int(i): j for j, i in enumerate(plan.free_idx)}
+        fixed_val = {int(i): float(v) for i, v in zip(plan.fixed_idx, plan.fixed_val)}
+        k = len(plan.kernel_idx)
+        fac = np.ones(k) if plan.kernel_fac is None else np.asarray(plan.kernel_fac, dtype=np.float64)
+        src, const = np.full(k, -1, dtype=np.int32), np.zeros(k)
+        for c, i in enumerate(plan.kernel_idx):
+            if int(i) in free_pos:
+                src[c] = free_pos[int(i)]
+            else:
+                const[c] = fixed_val[int(i)] * fac[c] if plan.kernel_fac is not None else fixed_val[int(i)]
+        fixed_ok = bool(np.all((plan.fixed_val >= plan.lo[plan.fixed_idx]) & (plan.fixed_val <= plan.hi[plan.fixed_idx]))) \
+            if plan.fixed_idx.size else True
+        out = {"col_source": src, "col_const": const, "col_factor": fac, "lo": plan.lo[plan.free_idx].copy(),
+               "hi": plan.hi[plan.free_idx].copy(), "fixed_ok": fixed_ok}
+        self._stretch_cache = (plan, out)
+        return out
+
+    def _stretch_block(self, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted):
+        """One block of stretch-move steps inside the library (``_native.Catalog.stretch_move``)."""
+        plan = self._plan()
+        if not plan.simple:
+            raise RuntimeError("the parameter configuration changed to one with expression priors / constraints during a run")
+        if self._context is not None and getattr(self._context, "n_ranks", 1) > 1:
+            self._check_ranks_agree(pos)
+        cat = self._catalog
+        if cat is None or plan.catalog_key != self._catalog_key:
+            cat = self._ensure_catalog()
+        cat.stretch_move(self._stretch_plan(), pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted)
 
     def __call__(self, n_walkers=100, n_steps=500, n_burn=100, n_threads=1, n_out=None, pos=None, lnprob0=None,
                  plot=False, prefix="sampler", true_values=None, **kwargs):

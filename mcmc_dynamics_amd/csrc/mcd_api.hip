@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>   // types and prototypes only: librccl.so is dlopen'ed on first multi-GPU use
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,7 @@
 #include "mcd_internal.h"
 #include "mcd_guard.h"
 #include "mcd_math.h"
+#include "mcd_stretch.h"
 
 namespace {
 
@@ -170,6 +172,7 @@ struct mcd_catalog {
     bool zero_copy = true;             // blocking call reads params / writes results through mapped pinned memory
     int64_t timing_stride = 1;         // "timing" = 2: event pair on every n-th launch only (option "timing_stride")
     int64_t timing_launches = 0;
+    int64_t spin_us = 20000;           // option "spin_us": poll a stream this long before blocking in hipStreamSynchronize
     int tail_split = 1;                // guided chunk schedule (shorter chunks at the end of a launch)
     int64_t target_waves = 12288;
     int64_t chunk_len = 0;             // option "chunk_len": explicit nominal chunk length (0: from target_waves)
@@ -276,6 +279,24 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     return MCD_OK;
 }
 
+// Wait for a stream: poll it (hipStreamQuery) for up to `spin_us` microseconds before handing the thread to the blocking
+// hipStreamSynchronize.  A blocking wait that lasts more than a fraction of a millisecond sleeps on an interrupt and
+// wakes the host 50 - 500 us after the device is done (measured as jitter of a 4 ms timed region, tools/k20_probe.py); an
+// MCMC driver has nothing else to do with its thread while an evaluation is in flight, so it polls (option "spin_us",
+// default 20000; 0 = always block).
+hipError_t wait_stream(hipStream_t s, int64_t spin_us) {
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    return hipStreamSynchronize(s);
+}
+
 // Work buffers staged for walker count W (nullptr when the cache no longer holds them, e.g. after a failed upload)
 WorkSet* find_work(Shard& sh, int64_t W) {
     const auto it = sh.work.find(W);
@@ -314,7 +335,7 @@ int stage_params_impl(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         // the pinned staging buffer may still be in flight from the previous call
-        MCD_HIP(hipStreamSynchronize(slot.stream));
+        MCD_HIP(wait_stream(slot.stream, cat->spin_us));
         std::memcpy(w->h_params, params, (size_t)n_rows * k * sizeof(double));
         // Blocking single-device call: the walker-prep kernel reads the pinned host table over PCIe and the reduce
         // kernel writes the results straight into pinned host memory -- no copy-engine operations on the critical
@@ -461,8 +482,8 @@ int sync_all(mcd_catalog* cat) {
     for (Shard& sh : cat->shards) {
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
-        MCD_HIP(hipStreamSynchronize(slot.stream));
-        MCD_HIP(hipStreamSynchronize(slot.comm_stream));
+        MCD_HIP(wait_stream(slot.stream, cat->spin_us));
+        MCD_HIP(wait_stream(slot.comm_stream, cat->spin_us));
     }
     if (cat->timing && cat->timing_pending) {
         Shard& sh = cat->shards[0];
@@ -894,6 +915,37 @@ int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t
     return MCD_OK;
 }
 
+int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
+                     const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
+                     double* lnprob_chain, int64_t* accepted) {
+    if (!cat || !d || !pos || !lnp || !order || !zz || !thr || !pick) return fail(MCD_ERR_INVALID, "mcd_stretch_move: null argument");
+    if (cat->n_psets != 1) return fail(MCD_ERR_INVALID, "mcd_stretch_move: un-binned catalogues only");
+    if (d->k != cat->k) return fail(MCD_ERR_INVALID, "mcd_stretch_move: descriptor has the wrong number of kernel columns");
+    if (d->n_walkers <= 0 || (d->n_walkers & 1) || d->n_dim <= 0 || n_steps < 0)
+        return fail(MCD_ERR_INVALID, "mcd_stretch_move: n_walkers must be positive and even, n_dim positive");
+    if (!d->col_source || !d->col_const || !d->col_factor || !d->lo || !d->hi) return fail(MCD_ERR_INVALID, "mcd_stretch_move: null descriptor array");
+    for (int c = 0; c < d->k; ++c)
+        if (d->col_source[c] >= d->n_dim) return fail(MCD_ERR_INVALID, "mcd_stretch_move: col_source outside the free parameters");
+    const int64_t W = d->n_walkers, half = W / 2;
+    for (int64_t i = 0; i < n_steps * W; ++i)
+        if (order[i] < 0 || order[i] >= W) return fail(MCD_ERR_INVALID, "mcd_stretch_move: order holds an index outside 0..W-1");
+    for (int64_t i = 0; i < n_steps * W; ++i)
+        if (pick[i] < 0 || pick[i] >= half) return fail(MCD_ERR_INVALID, "mcd_stretch_move: pick holds an index outside the half ensemble");
+    mcd::StretchDesc sd;
+    sd.n_walkers = W; sd.n_dim = d->n_dim; sd.k = d->k; sd.col_source = d->col_source; sd.col_const = d->col_const;
+    sd.col_factor = d->col_factor; sd.lo = d->lo; sd.hi = d->hi; sd.fixed_ok = d->fixed_ok;
+    int eval_rc = MCD_OK;
+    const int rc = mcd::stretch_block(sd, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted,
+                                      [&](const double* table, int64_t n, double* out) {
+                                          eval_rc = mcd_loglike_batch(cat, n, d->k, table, out);
+                                          return eval_rc;
+                                      });
+    if (rc == mcd::STRETCH_EVAL_FAILED) return eval_rc;                  // message already set by mcd_loglike_batch
+    if (rc == mcd::STRETCH_NAN) return fail(MCD_ERR_NONFINITE, "mcd_stretch_move: the log-likelihood returned NaN");
+    if (rc != mcd::STRETCH_OK) return fail(MCD_ERR_INVALID, "mcd_stretch_move: bad arguments");
+    return MCD_OK;
+}
+
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
     if (!cat || !key) return fail(MCD_ERR_INVALID, "mcd_set_option: null argument");
     if (!std::strcmp(key, "timing")) {
@@ -941,6 +993,11 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     if (!std::strcmp(key, "zero_copy")) { cat->zero_copy = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "spin_us")) {
+        if (value < 0) return fail(MCD_ERR_INVALID, "spin_us must be >= 0");
+        cat->spin_us = value;
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "tail_split") || !std::strcmp(key, "target_waves") || !std::strcmp(key, "chunk_len")) {
         const bool is_split = !std::strcmp(key, "tail_split"), is_len = !std::strcmp(key, "chunk_len");
         if (!is_split && !is_len && value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");

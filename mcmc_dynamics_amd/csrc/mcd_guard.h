@@ -23,7 +23,18 @@ struct CatalogStats {
     // indices; the kernel then takes the general fast form for those chunks only (LaunchShape::chunk_general).
     std::vector<int64_t> narrow_exceptions;
     bool narrow_possible = false;                   // at most 1/8 of the stars are exceptions (else: general form throughout)
+    bool f32_mixture_ok = false;                    // background columns inside the ranges of the float32 fast mixtures
 };
+
+// float32 fast mixtures (BgFixedAccF / BgGaussAccF): four mixture values are multiplied between two rescales in float, so
+// every y must stay within [2^-27, 2^31]:  pmember <= 1 - 2^-20 and -12 <= lnL_bg <= 60 (y = (1 - p) + g e^{..} <= 1 +
+// 2^7.5 e^13);  densities (and f_back, per call) within [2^-20, 4];  variances within [2^-15, 2^15] (per call).
+inline bool f32_mixture_star_ok(int bg, double lnbg, double pm, double rho) {
+    if (bg == BG_FIXED) return pm >= 0.0 && pm <= 1.0 - 0x1p-20 && lnbg >= -12.0 && lnbg <= 60.0;
+    if (bg == BG_GAUSS) return rho >= 0x1p-20 && rho <= 4.0;
+    if (bg == BG_FIXED_DENSITY) return rho >= 0x1p-20 && rho <= 4.0 && lnbg >= -12.0 && lnbg <= 60.0;
+    return true;
+}
 
 // BGFIXED: a certain member (pmember == 1: the mixture value y = (1 - p) + ... has no floor) or lnL_bg < -60 (y can
 // exceed 2^120: eight raw factors no longer fit between two rescales).  BGGAUSS family: density outside [2^-20, 2^20]
@@ -41,7 +52,10 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
     CatalogStats st;
     double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
     double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
-    bool finite = true, ok = true;
+    bool finite = true, ok = true, f32_ok = bg != BG_NONE;
+    for (int64_t i = 0; i < n && f32_ok; ++i)
+        f32_ok = f32_mixture_star_ok(bg, lnbg ? lnbg[i] : 0.0, pmember ? pmember[i] : 0.0, density ? density[i] : 1.0);
+    st.f32_mixture_ok = f32_ok;
     for (int64_t i = 0; i < n; ++i) {
         const double e2 = verr[i] * verr[i];
         const double av = std::fabs(v[i]);
@@ -99,7 +113,7 @@ struct GuardRanges {
 inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
                        int64_t n_rows, GuardRanges* ranges = nullptr) {
     if (!st.stats_finite || n_rows == 0) return false;
-    if (f32 && bg_kind(model) != BG_NONE) return false;      // f32 mixtures use the plain kernels
+    if (f32 && bg_kind(model) != BG_NONE && !st.f32_mixture_ok) return false;   // f32 mixtures outside their ranges: plain kernels
     const bool prof = is_profile(model);
     const int bg = bg_kind(model);
     const int ix = prof ? 3 : 2, iy = prof ? 4 : 3;
@@ -152,6 +166,16 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
                    (!prof || (len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20)));
         // 16-star tree of MODEL_CONST: DEN = prod of 16 norms within 2^+-880, NUM <= q norm^15 <= 2^100 2^825
         return (n_min >= std::ldexp(1.0, -55)) && (n_max <= std::ldexp(1.0, 55)) && (d_max <= std::ldexp(1.0, 50));
+    }
+    if (f32) {
+        // float32 fast mixtures: variances and residuals inside the float range of (d g)^2, per-walker f_back and
+        // sigma_back inside the ranges that keep four mixture values within float between rescales (f32_mixture_star_ok)
+        const double flo = std::ldexp(1.0, -15), fhi = std::ldexp(1.0, 15);
+        if (!(n_min >= flo && n_max <= fhi && d_max <= fhi && st.extras_ok)) return false;
+        if (prof && !(len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20))) return false;
+        if (bg == BG_GAUSS && !(st.e2_min + sb2_min >= flo && st.e2_max + sb2_max <= fhi)) return false;
+        if ((bg == BG_GAUSS || bg == BG_FIXED_DENSITY) && !(f_min >= std::ldexp(1.0, -20) && f_max <= 4.0)) return false;
+        return true;
     }
     const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
     if (!((n_min >= lo) && (n_max <= hi))) return false;

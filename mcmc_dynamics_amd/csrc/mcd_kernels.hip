@@ -310,15 +310,15 @@ hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* re
                 return launch_one<MODEL, FREE, double, double, 1>(s, records, chunks, n_chunks, wpar, partials,
                                                                   n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
             return launch_one<MODEL, FREE, double, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
-        case 1:
-            if (sh.fast && bg_kind(MODEL) == BG_NONE)
-                return launch_one<MODEL, FREE, float, float, bg_kind(MODEL) == BG_NONE ? 1 : 0>(s, records, chunks, n_chunks, wpar,
-                                                                                       partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+        case 1:      // float32 terms and sums: fast formulations for every model when the f32 guard admits them (mcd_guard.h)
+            if (sh.fast)
+                return launch_one<MODEL, FREE, float, float, 1>(s, records, chunks, n_chunks, wpar, partials, n_walkers,
+                                                                uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
             return launch_one<MODEL, FREE, float, float, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
-        case 2:
-            if (sh.fast && bg_kind(MODEL) == BG_NONE)
-                return launch_one<MODEL, FREE, float, double, bg_kind(MODEL) == BG_NONE ? 1 : 0>(s, records, chunks, n_chunks, wpar,
-                                                                                        partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+        case 2:      // float32 terms, float64 accumulation
+            if (sh.fast)
+                return launch_one<MODEL, FREE, float, double, 1>(s, records, chunks, n_chunks, wpar, partials, n_walkers,
+                                                                 uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
             return launch_one<MODEL, FREE, float, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
     }
     return hipErrorInvalidValue;

@@ -619,6 +619,98 @@ struct BgGaussAcc {
 };
 
 // ---------------------------------------------------------------------------------------------
+// float32 fast mixtures (MCD_F32 / MCD_F32_ACC64): the same formulations with v_rsq_f32 / v_exp_f32 (1 ulp each, no
+// Newton step, no table) and the running products in A = float or double.  Valid under the f32 conditions of
+// mcd_guard.h (fast_guard): every mixture value y lies in [2^-27, 2^31], so four factors fit between two rescales.
+MCD_HD float rsqf_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / std::sqrt(x);
+#endif
+}
+MCD_HD float expf_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);      // v_exp_f32; arguments below -126 / ln 2 flush to 0
+#else
+    return std::exp(x);
+#endif
+}
+template <class A>
+struct LogProductF {                 // sum of logs as log of a product, mantissa in A, exponent in an int
+    A p;
+    int e;
+    MCD_HD void init() { p = 1; e = 0; }
+    MCD_HD void mul(float x) { p *= (A)x; }
+    MCD_HD void rescale() {
+        int ex;
+        if constexpr (sizeof(A) == 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            p = __builtin_frexp(p, &ex);
+#else
+            p = std::frexp(p, &ex);
+#endif
+        } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+            p = __builtin_frexpf(p, &ex);
+#else
+            p = std::frexp(p, &ex);
+#endif
+        }
+        e += ex;
+    }
+    MCD_HD double value() {
+        rescale();
+#if defined(__HIP_DEVICE_COMPILE__)
+        return fma_((double)e, kLn2, log((double)p));
+#else
+        return fma_((double)e, kLn2, std::log((double)p));
+#endif
+    }
+};
+// BG_FIXED / BG_FIXED_DENSITY:  y = w0 + g exp(nbp - 1/2 d^2 g^2),  w0 = 1 - p (record) or f_back (walker)
+template <class A>
+struct BgFixedAccF {
+    LogProductF<A> l, lden;
+    MCD_HD void init() { l.init(); lden.init(); }
+    MCD_HD void add(float d, float n, float w0, float nbp) {
+        const float g = rsqf_(n);
+        const float dg = d * g;
+        l.mul(fma_(g, expf_(fma_(-0.5f * dg, dg, nbp)), w0));
+    }
+    MCD_HD void add_density(float d, float n, float rho, float f, float nbp) {
+        add(d, n, f, nbp);
+        lden.mul(rho + f);
+    }
+    MCD_HD void rescale() { l.rescale(); }
+    MCD_HD void rescale_density() { l.rescale(); lden.rescale(); }
+    MCD_HD double finish() { return l.value(); }
+    MCD_HD double finish_density() { return l.value() - lden.value(); }
+};
+// BG_GAUSS:  y = rho g + f gb e^{-delta} (or mirrored), as BgGaussAcc
+template <class A>
+struct BgGaussAccF {
+    A sum_min;
+    LogProductF<A> ly, lden;
+    MCD_HD void init() { sum_min = 0; ly.init(); lden.init(); }
+    MCD_HD void add(float d, float n, float db, float nb, float rho, float f) {
+        const float g = rsqf_(n), gb = rsqf_(nb);
+        const float dg = d * g, dbg = db * gb;
+        const float w = dg * dg, wb = dbg * dbg;
+        const float t = wb - w;
+        const float e = expf_(-0.5f * (t < 0.0f ? -t : t));
+        const float a = rho * g, b = f * gb;
+        ly.mul(t >= 0.0f ? fma_(b, e, a) : fma_(a, e, b));
+        lden.mul(rho + f);
+        sum_min += (A)(w < wb ? w : wb);
+    }
+    MCD_HD void rescale() { ly.rescale(); lden.rescale(); }
+    MCD_HD double finish(int64_t count) {
+        return fma_(-(double)count, kHalfLn2Pi, -0.5 * (double)sum_min) + (ly.value() - lden.value());
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // background.SingleStars (single_stars.py:42-77): one test star against a slice of the comparison stars.
 //   e_j = -(c_j - v)^2 h,  h = 1 / (2 (verr^2 + sigma_int^2));   slice result: nearest distance + sum_j exp(e_j - e_max)
 // Two passes over the slice: the nearest comparison star gives the largest exponent exactly, every term of the
@@ -714,7 +806,46 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
     constexpr int BG = bg_kind(MODEL);
     double result;
 
-    if constexpr (BG == BG_NONE && FAST && sizeof(T) == 4) {
+    if constexpr (BG != BG_NONE && FAST && sizeof(T) == 4) {
+        // float32 fast mixtures: four stars (one scalar record batch) per rescale; A = float or double
+        auto run4 = [&](auto& acc, auto&& one, auto&& rescale) {
+            const int n4 = count >> 2;
+            for (int g = 0; g < n4; ++g, r += 4 * ND) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) one(r + j * ND);
+                rescale();
+            }
+            for (int j = n4 * 4; j < count; ++j, r += ND) { one(r); rescale(); }
+        };
+        if constexpr (BG == BG_GAUSS) {
+            BgGaussAccF<A> acc;
+            acc.init();
+            run4(acc, [&](const T* rr) {
+                T d, n;
+                star_d_n<MODEL, T, FREE, true>(rr, w, d, n);
+                acc.add(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb);
+            }, [&]() { acc.rescale(); });
+            result = acc.finish(count);
+        } else if constexpr (BG == BG_FIXED) {
+            BgFixedAccF<A> acc;
+            acc.init();
+            run4(acc, [&](const T* rr) {
+                T d, n;
+                star_d_n<MODEL, T, FREE, true>(rr, w, d, n);
+                acc.add(d, n, rr[XB + 2], rr[XB + 3]);
+            }, [&]() { acc.rescale(); });
+            result = acc.finish();
+        } else {
+            BgFixedAccF<A> acc;
+            acc.init();
+            run4(acc, [&](const T* rr) {
+                T d, n;
+                star_d_n<MODEL, T, FREE, true>(rr, w, d, n);
+                acc.add_density(d, n, rr[XB + 2], w.fb, rr[XB + 1]);
+            }, [&]() { acc.rescale_density(); });
+            result = acc.finish_density();
+        }
+    } else if constexpr (BG == BG_NONE && FAST && sizeof(T) == 4) {
         // f32 fraction tree over 4 stars + f32 log-product.  One iteration covers 16 stars (four trees) so that four
         // 64-byte scalar record loads are in flight per wave: a 4-star iteration is only ~40 ns of VALU work, far
         // less than one load latency even with 8 waves per SIMD.

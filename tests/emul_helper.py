@@ -23,7 +23,7 @@ def lib():
     global _lib
     if _lib is None:
         deps = [SRC, os.path.join(INC, "mcd_math.h"), os.path.join(INC, "mcd_guard.h"),
-                os.path.join(INC, "mcd_exp_table.h"), os.path.join(INC, "mcd_chunks.h")]
+                os.path.join(INC, "mcd_exp_table.h"), os.path.join(INC, "mcd_chunks.h"), os.path.join(INC, "mcd_stretch.h")]
         if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", INC, SRC,
                             "-o", OUT], check=True)

@@ -135,6 +135,45 @@ def test_mcmc_on_example_catalogue(tmp_path):
     assert np.asarray(sampler2.chain).shape == (32, 5, 4)
 
 
+@pytest.mark.parametrize("case", ["bg fixed centre", "gb free centre", "one kernel column fixed"])
+def test_library_stretch_move_equals_the_python_loop(case):
+    """`mcd_stretch_move` (the half-step loop in C++, csrc/mcd_stretch.h, what Runner's built-in sampler uses for box
+    priors) produces bit-identical chains to the Python loop of sampler.py driving `lnprob_batch` (runner.py:403-419)."""
+    from mcmc_dynamics_amd import DataReader, Gaussian, synthetic
+    from mcmc_dynamics_amd.analysis import ConstantFit, ConstantFitGB
+    from mcmc_dynamics_amd.sampler import EnsembleSampler
+    cat = synthetic.make_catalog(20000, config=3, background=True)
+    centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
+    names = ["v_sys", "sigma_max", "v_maxx", "v_maxy"]
+    if case == "gb free centre":
+        fit = ConstantFitGB(DataReader({k: cat[k] for k in ("ra", "dec", "v", "verr", "density")}))
+        fit.parameters["ra_center"].set(value=centre[0])
+        fit.parameters["dec_center"].set(value=centre[1])
+        names = names + ["ra_center", "dec_center", "v_back", "sigma_back", "f_back"]
+    else:
+        fit = ConstantFit(DataReader({k: cat[k] for k in ("ra", "dec", "v", "verr", "pmember")}), background=Gaussian(20.0, 40.0))
+        fit.parameters["ra_center"].set(value=centre[0], fixed=True)
+        fit.parameters["dec_center"].set(value=centre[1], fixed=True)
+        if case == "one kernel column fixed":
+            fit.parameters["v_sys"].set(value=0.3, fixed=True)
+            names = names[1:]
+    assert fit.fitted_parameters == names
+    pos = synthetic.make_walkers(32, names, cat["truth"], config=3)
+    pos[:, names.index("sigma_max")] = np.abs(pos[:, names.index("sigma_max")] * (1.0 + 0.5 * np.random.default_rng(1).normal(size=32)))
+    native = fit._make_sampler(32, seed=11)
+    assert isinstance(native, EnsembleSampler) and native.block_fn is not None
+    native.run_mcmc(pos, 70)                                # a 64-step block and a 6-step block
+    python = EnsembleSampler(32, len(names), fit.lnprob_batch, vectorize=True, seed=11)
+    python.run_mcmc(pos, 70)
+    assert np.array_equal(native.chain, python.chain) and np.array_equal(native.lnprobability, python.lnprobability)
+    assert np.array_equal(native.acceptance_fraction, python.acceptance_fraction) and native.n_calls == python.n_calls
+    assert 0.05 < native.acceptance_fraction.mean() < 0.95 and np.all(np.isfinite(native.lnprobability))
+    # through Runner.__call__ as a user would (restarts every n_out steps included)
+    run = fit(n_walkers=32, n_steps=20, n_out=10, pos=pos, prefix=None)
+    assert np.asarray(run.chain).shape == (32, 20, len(names))
+    fit.close()
+
+
 # ------------------------------------------------------------------------------------------ ModelFit family ("next" row 1)
 @pytest.mark.parametrize("which", ["fixed", "free"])
 def test_model_fit(which):

@@ -1,0 +1,103 @@
+"""csrc/mcd_stretch.h on the CPU: the library's stretch-move block (what mcd_stretch_move runs between kernel launches)
+against the Python loop of mcmc_dynamics_amd/sampler.py from the same generator state -- bit-identical chains, prior box
+handling included.  The likelihood is a Python callback here; on the GPU it is mcd_loglike_batch (tests/test_gpu_runner.py)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import emul_helper as em
+from mcmc_dynamics_amd.sampler import EnsembleSampler
+
+EVAL = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int64, ctypes.POINTER(ctypes.c_double))
+
+
+def _lnlike(table):
+    """Some smooth function of the kernel table rows (a correlated Gaussian with a banana): (n, K) -> (n,)."""
+    t = np.asarray(table)
+    return -0.5 * ((t[:, 0] - 1.0) ** 2 / 0.5 + (t[:, 1] - 0.1 * t[:, 0] ** 2) ** 2 / 2.0 + np.sum(t[:, 2:] ** 2, axis=1))
+
+
+def _block_fn(src, const, fac, lo, hi, fixed_ok, calls):
+    lib = em.lib()
+    k = len(src)
+
+    @EVAL
+    def cb(tab, n, out):
+        table = np.ctypeslib.as_array(tab, shape=(n, k))
+        calls.append(table.copy())
+        res = _lnlike(table)
+        np.ctypeslib.as_array(out, shape=(n,))[:] = res
+        return 0
+
+    def run(pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted):
+        p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t)) if a is not None else None
+        rc = lib.emul_stretch_block(ctypes.c_int64(pos.shape[0]), pos.shape[1], k, p(src, ctypes.c_int32), p(const, ctypes.c_double),
+                                    p(fac, ctypes.c_double), p(lo, ctypes.c_double), p(hi, ctypes.c_double), int(fixed_ok),
+                                    ctypes.c_int64(order.shape[0]), p(pos, ctypes.c_double), p(lnp, ctypes.c_double),
+                                    p(order, ctypes.c_int32), p(zz, ctypes.c_double), p(thr, ctypes.c_double), p(pick, ctypes.c_int32),
+                                    p(chain, ctypes.c_double), p(lnprob_chain, ctypes.c_double), p(accepted, ctypes.c_int64), cb)
+        assert rc == 0, rc
+    run.keep = cb
+    return run
+
+
+@pytest.mark.parametrize("case", ["identity", "fixed column and unit factor", "tight bounds"])
+def test_library_stretch_block_equals_the_python_loop(case):
+    P = 4
+    lo, hi = np.full(P, -np.inf), np.full(P, np.inf)
+    if case == "identity":
+        src, const, fac = np.arange(P, dtype=np.int32), np.zeros(P), np.ones(P)
+    elif case == "fixed column and unit factor":
+        # kernel table: [free 0, fixed 0.25, free 1 x 60 (arcmin -> arcsec), free 3, free 2]
+        src, const, fac = np.array([0, -1, 1, 3, 2], dtype=np.int32), np.array([0, 0.25, 0, 0, 0.0]), np.array([1, 1, 60.0, 1, 1.0])
+    else:
+        src, const, fac = np.arange(P, dtype=np.int32), np.zeros(P), np.ones(P)
+        lo, hi = np.array([0.2, -np.inf, -0.8, -np.inf]), np.array([np.inf, 1.5, 0.9, np.inf])     # many proposals rejected
+
+    def lnprob(values):                                   # what Runner.lnprob_batch does for a box prior
+        values = np.atleast_2d(values)
+        ok = ~np.isnan(values).any(axis=1) & (values >= lo).all(axis=1) & (values <= hi).all(axis=1)
+        out = np.full(len(values), -np.inf)
+        if ok.any():
+            v = values.copy()
+            v[~ok] = v[int(np.flatnonzero(ok)[0])]
+            table = np.where(src >= 0, v[:, np.maximum(src, 0)] * fac, const)
+            out[ok] = _lnlike(table)[ok]
+        return out
+
+    rng = np.random.default_rng(1)
+    start = np.array([1.0, 0.3, 0.0, 0.0]) + 0.3 * rng.normal(size=(24, P))
+    start[:, 0] = np.abs(start[:, 0]) + 0.25
+    start[:, 2] = np.clip(start[:, 2], -0.7, 0.8)
+    start[:, 1] = np.minimum(start[:, 1], 1.4)
+    ref = EnsembleSampler(24, P, lnprob, vectorize=True, seed=77)
+    ref.run_mcmc(start, 150)
+    calls = []
+    nat = EnsembleSampler(24, P, lnprob, vectorize=True, seed=77, block_fn=_block_fn(src, const, fac, lo, hi, True, calls))
+    pos, lnp, _ = nat.run_mcmc(start, 150)
+    assert np.array_equal(nat.chain, ref.chain) and np.array_equal(nat.lnprobability, ref.lnprobability)
+    assert np.array_equal(nat.acceptance_fraction, ref.acceptance_fraction) and nat.n_calls == ref.n_calls
+    assert np.array_equal(pos, ref.chain[:, -1, :]) and nat.iteration == 150
+    assert 0.1 < nat.acceptance_fraction.mean() < 0.9
+    assert all(c.shape == (12, len(src)) for c in calls)
+    if case == "tight bounds":
+        assert np.all(nat.chain[..., 0] >= 0.2) and np.all(nat.chain[..., 2] <= 0.9)          # never accepted outside the box
+        assert np.any(~np.isfinite(lnprob(np.array([[0.1, 0, 0, 0.0]]))))
+    if case != "identity":
+        assert all(np.all(c[:, 1] == 0.25) for c in calls) if case.startswith("fixed") else True
+    # a second run continues from the state (restart semantics of Runner.__call__ with n_out)
+    ref.run_mcmc(ref.chain[:, -1, :], 70, log_prob0=ref.lnprobability[:, -1])
+    nat.run_mcmc(pos, 70, log_prob0=lnp)
+    assert np.array_equal(nat.chain, ref.chain) and nat.chain.shape == (24, 220, P)
+
+
+def test_fixed_parameter_outside_its_bounds_rejects_everything():
+    src, const, fac = np.arange(4, dtype=np.int32), np.zeros(4), np.ones(4)
+    lo, hi = np.full(4, -np.inf), np.full(4, np.inf)
+    calls = []
+    start = np.random.default_rng(2).normal(size=(16, 4))
+    s = EnsembleSampler(16, 4, lambda v: np.full(len(v), -np.inf), vectorize=True, seed=3,
+                        block_fn=_block_fn(src, const, fac, lo, hi, False, calls))
+    pos, lnp, _ = s.run_mcmc(start, 10, log_prob0=np.zeros(16))
+    assert np.array_equal(pos, start) and not calls and np.all(s.acceptance_fraction == 0)
