@@ -10,6 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from mcmc_dynamics_amd import distributed, synthetic                      # noqa: E402
 from mcmc_dynamics_amd.hostgroup import HostGroup                         # noqa: E402
@@ -31,6 +32,30 @@ class ShardCatalog(object):
         self.calls += 1
         return self.group.allreduce(oracle.batched_constant_lnlike(self.shard, np.asarray(table), *self.centre), op="sum")
 
+    def stretch_move(self, plan, pos, lnp, order, zz, thr, pick, chain=None, lnprob_chain=None, accepted=None):
+        """`_native.Catalog.stretch_move` with the library's own half-step loop (csrc/mcd_stretch.h, host build of
+        tests/emul) around this stub's sharded likelihood."""
+        import ctypes
+        import emul_helper
+        lib = emul_helper.lib()
+        k = len(plan["col_source"])
+        fn_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int64, ctypes.POINTER(ctypes.c_double))
+
+        @fn_t
+        def cb(tab, n, out):
+            np.ctypeslib.as_array(out, shape=(n,))[:] = self.loglike(np.ctypeslib.as_array(tab, shape=(n, k)).copy())
+            return 0
+        cols = [np.ascontiguousarray(plan["col_source"], dtype=np.int32)] + \
+            [np.ascontiguousarray(plan[key], dtype=np.float64) for key in ("col_const", "col_factor", "lo", "hi")]
+        ptr = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t)) if a is not None else None
+        rc = lib.emul_stretch_block(ctypes.c_int64(pos.shape[0]), pos.shape[1], k, ptr(cols[0], ctypes.c_int32),
+                                    *[ptr(c, ctypes.c_double) for c in cols[1:]], int(plan.get("fixed_ok", True)),
+                                    ctypes.c_int64(order.shape[0]), ptr(pos, ctypes.c_double), ptr(lnp, ctypes.c_double),
+                                    ptr(order, ctypes.c_int32), ptr(zz, ctypes.c_double), ptr(thr, ctypes.c_double),
+                                    ptr(pick, ctypes.c_int32), ptr(chain, ctypes.c_double), ptr(lnprob_chain, ctypes.c_double),
+                                    ptr(accepted, ctypes.c_int64), cb)
+        assert rc == 0
+
     def close(self):
         pass
 
@@ -39,6 +64,10 @@ def main():
     assert "torch" not in sys.modules
     rank, world, _ = distributed.env_rank()
     group = HostGroup.from_env(timeout=120)
+    if rank == 0:                                   # build the host test library once, not concurrently in every rank
+        import emul_helper
+        emul_helper.lib()
+    group.barrier()
     centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
     full = synthetic.make_catalog(4001, config=4)                    # odd size: uneven shards
     names = ["v_sys", "sigma_max", "v_maxx", "v_maxy"]
