@@ -23,18 +23,8 @@ struct CatalogStats {
     // indices; the kernel then takes the general fast form for those chunks only (LaunchShape::chunk_general).
     std::vector<int64_t> narrow_exceptions;
     bool narrow_possible = false;                   // at most 1/8 of the stars are exceptions (else: general form throughout)
-    bool f32_mixture_ok = false;                    // background columns inside the ranges of the float32 fast mixtures
+    double lnbg_min = 0, lnbg_max = 0, pm_max = 0;  // ranges of the fixed background columns (float32 fast mixtures)
 };
-
-// float32 fast mixtures (BgFixedAccF / BgGaussAccF): four mixture values are multiplied between two rescales in float, so
-// every y must stay within [2^-27, 2^31]:  pmember <= 1 - 2^-20 and -12 <= lnL_bg <= 60 (y = (1 - p) + g e^{..} <= 1 +
-// 2^7.5 e^13);  densities (and f_back, per call) within [2^-20, 4];  variances within [2^-15, 2^15] (per call).
-inline bool f32_mixture_star_ok(int bg, double lnbg, double pm, double rho) {
-    if (bg == BG_FIXED) return pm >= 0.0 && pm <= 1.0 - 0x1p-20 && lnbg >= -12.0 && lnbg <= 60.0;
-    if (bg == BG_GAUSS) return rho >= 0x1p-20 && rho <= 4.0;
-    if (bg == BG_FIXED_DENSITY) return rho >= 0x1p-20 && rho <= 4.0 && lnbg >= -12.0 && lnbg <= 60.0;
-    return true;
-}
 
 // BGFIXED: a certain member (pmember == 1: the mixture value y = (1 - p) + ... has no floor) or lnL_bg < -60 (y can
 // exceed 2^120: eight raw factors no longer fit between two rescales).  BGGAUSS family: density outside [2^-20, 2^20]
@@ -52,10 +42,16 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
     CatalogStats st;
     double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
     double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
-    bool finite = true, ok = true, f32_ok = bg != BG_NONE;
-    for (int64_t i = 0; i < n && f32_ok; ++i)
-        f32_ok = f32_mixture_star_ok(bg, lnbg ? lnbg[i] : 0.0, pmember ? pmember[i] : 0.0, density ? density[i] : 1.0);
-    st.f32_mixture_ok = f32_ok;
+    bool finite = true, ok = true;
+    if ((bg == BG_FIXED || bg == BG_FIXED_DENSITY) && n > 0) {
+        st.lnbg_min = std::numeric_limits<double>::infinity();
+        st.lnbg_max = -st.lnbg_min;
+        for (int64_t i = 0; i < n; ++i) {
+            st.lnbg_min = std::min(st.lnbg_min, lnbg[i]);
+            st.lnbg_max = std::max(st.lnbg_max, lnbg[i]);
+            if (bg == BG_FIXED) st.pm_max = std::max(st.pm_max, pmember[i]);
+        }
+    }
     for (int64_t i = 0; i < n; ++i) {
         const double e2 = verr[i] * verr[i];
         const double av = std::fabs(v[i]);
@@ -113,7 +109,7 @@ struct GuardRanges {
 inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
                        int64_t n_rows, GuardRanges* ranges = nullptr) {
     if (!st.stats_finite || n_rows == 0) return false;
-    if (f32 && bg_kind(model) != BG_NONE && !st.f32_mixture_ok) return false;   // f32 mixtures outside their ranges: plain kernels
+
     const bool prof = is_profile(model);
     const int bg = bg_kind(model);
     const int ix = prof ? 3 : 2, iy = prof ? 4 : 3;
@@ -168,14 +164,31 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
         return (n_min >= std::ldexp(1.0, -55)) && (n_max <= std::ldexp(1.0, 55)) && (d_max <= std::ldexp(1.0, 50));
     }
     if (f32) {
-        // float32 fast mixtures: variances and residuals inside the float range of (d g)^2, per-walker f_back and
-        // sigma_back inside the ranges that keep four mixture values within float between rescales (f32_mixture_star_ok)
+        // float32 fast mixtures (BgFixedAccF / BgGaussAccF): four mixture values y are multiplied in float between two
+        // rescales, so every y must stay within [2^-30, 2^30]; variances and residuals inside the float range of (d g)^2.
         const double flo = std::ldexp(1.0, -15), fhi = std::ldexp(1.0, 15);
         if (!(n_min >= flo && n_max <= fhi && d_max <= fhi && st.extras_ok)) return false;
         if (prof && !(len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20))) return false;
-        if (bg == BG_GAUSS && !(st.e2_min + sb2_min >= flo && st.e2_max + sb2_max <= fhi)) return false;
-        if ((bg == BG_GAUSS || bg == BG_FIXED_DENSITY) && !(f_min >= std::ldexp(1.0, -20) && f_max <= 4.0)) return false;
-        return true;
+        const double g_max_log2 = -0.5 * std::log2(n_min), kLog2e = 1.4426950408889634;
+        if (bg == BG_FIXED) {
+            // y = (1 - p) + g e^{u},  u <= log p - lnL_bg - 1/2 log 2pi:  lower bound 1 - p, upper 1 + g_max e^{-lnL_bg,min}
+            if (!(st.pm_max <= 1.0 - 0x1p-20 && st.lnbg_max <= 60.0 && st.lnbg_min >= -80.0)) return false;
+            return std::max(0.0, -(st.lnbg_min + kHalfLn2Pi) * kLog2e + g_max_log2) + 1.0 <= 30.0;
+        }
+        if (bg == BG_FIXED_DENSITY) {
+            // y = f + g e^{u},  u <= log rho - lnL_bg - 1/2 log 2pi
+            if (!(f_min >= 0x1p-20 && f_max <= 0x1p20 && st.rho_min >= 0.0 && st.lnbg_max <= 60.0 && st.lnbg_min >= -80.0)) return false;
+            const double up = std::log2(std::max(st.rho_max, 0x1p-60)) - (st.lnbg_min + kHalfLn2Pi) * kLog2e + g_max_log2;
+            return std::max(std::log2(f_max), up) + 1.0 <= 30.0 && st.rho_min + f_min >= 0x1p-30 && st.rho_max + f_max <= 0x1p30;
+        }
+        // BG_GAUSS: y = rho g + f gb e^{-delta} (or mirrored): between min and sum of the two undamped terms
+        if (!(st.e2_min + sb2_min >= flo && st.e2_max + sb2_max <= fhi)) return false;
+        if (!(f_min >= 0x1p-20 && f_max <= 0x1p20 && st.rho_min >= 0x1p-20 && st.rho_max <= 0x1p20)) return false;
+        const double gb_max_log2 = -0.5 * std::log2(st.e2_min + sb2_min);
+        const double g_min_log2 = -0.5 * std::log2(n_max), gb_min_log2 = -0.5 * std::log2(st.e2_max + sb2_max);
+        const double hi2 = std::max(std::log2(st.rho_max) + g_max_log2, std::log2(f_max) + gb_max_log2) + 1.0;
+        const double lo2 = std::min(std::log2(st.rho_min) + g_min_log2, std::log2(f_min) + gb_min_log2);
+        return hi2 <= 30.0 && lo2 >= -30.0;
     }
     const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
     if (!((n_min >= lo) && (n_max <= hi))) return false;

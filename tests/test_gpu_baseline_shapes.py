@@ -183,3 +183,85 @@ def test_binned_catalogue_with_more_than_256_walkers(native, ctx, model, n_walke
                 want = oracle.batched_constant_gb_lnlike(sub, params[b], *centre)
             assert rel_err(got[b], want) < RTOL, (fast, b)
     cat.close()
+
+
+def test_c3_exact_shape_precision_sweep(native, ctx):
+    """The C5-style precision sweep on C3 (1e6 stars x 256 walkers, fixed-Gaussian-background mixture): the float32 fast
+    mixtures (v_rsq_f32 / v_exp_f32, products in float or double) against float64.  Tolerances per walker log-likelihood:
+    f32 terms + f64 accumulation <= 1e-6, pure f32 <= 2e-5 relative (as for C5)."""
+    from mcmc_dynamics_amd import synthetic
+    from mcmc_dynamics_amd.background import Gaussian
+    c, centre = _catalog(1000000, 3, background=True)
+    lnbg = Gaussian(synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])(c["v"], c["verr"])
+    pos = synthetic.make_walkers(256, NAMES4, c["truth"], config=3)
+    out, level = {}, {}
+    for prec in ("f64", "f32acc64", "f32"):
+        cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=native.MODEL_CONST_BGFIXED, centre=centre,
+                             lnlike_bg=lnbg, pmember=c["pmember"], precision=prec)
+        out[prec] = cat.loglike(pos)
+        level[prec] = cat.fast_level
+        if prec != "f64":
+            cat.set_option("fast_path", 0)
+            out[prec + " plain"] = cat.loglike(pos)
+        cat.close()
+    assert level == {"f64": 2, "f32acc64": 1, "f32": 1}
+    assert rel_err(out["f32acc64"], out["f64"]) < 1e-6
+    assert rel_err(out["f32"], out["f64"]) < 2e-5
+    assert rel_err(out["f32acc64 plain"], out["f64"]) < 1e-6 and rel_err(out["f32 plain"], out["f64"]) < 2e-5
+
+
+@pytest.mark.parametrize("model", ["bgfixed", "bggauss", "profile_bgdens", "profile_bggauss", "profile_bgfixed"])
+@pytest.mark.parametrize("free", [False, True])
+def test_float32_fast_mixtures_against_float64(native, ctx, model, free):
+    """Every mixture model, fixed and free centre: float32 fast formulation (guard level 1) vs the float64 result, and the
+    fall-back to the plain float32 kernels when a star lies outside the float32 ranges (a certain member)."""
+    from mcmc_dynamics_amd import synthetic
+    from mcmc_dynamics_amd.background import Gaussian
+    c, centre = _catalog(50000, 3, background=True)
+    lnbg = Gaussian(synthetic.TRUTH["v_back"], synthetic.TRUTH["sigma_back"])(c["v"], c["verr"])
+    names = list(NAMES4)
+    rng = np.random.default_rng(3)
+    base = synthetic.make_walkers(96, NAMES4 + ["v_back", "sigma_back", "f_back"], c["truth"], config=3)
+    core = base[:, :4]
+    prof = model.startswith("profile")
+    if prof:
+        a = 30.0 * (1.0 + 0.05 * rng.normal(size=96))
+        rp = 60.0 * (1.0 + 0.05 * rng.normal(size=96))
+        core = np.column_stack([base[:, 0], base[:, 1], a, base[:, 2], base[:, 3], rp])
+    cols = [core]
+    if free:
+        cols.append(np.column_stack([centre[0] + 1e-3 * rng.normal(size=96), centre[1] + 1e-3 * rng.normal(size=96)]))
+    kw = {}
+    if model in ("bgfixed", "profile_bgfixed"):
+        kw = dict(lnlike_bg=lnbg, pmember=c["pmember"])
+    elif model in ("bggauss", "profile_bggauss"):
+        kw = dict(density=c["density"])
+        cols.append(np.column_stack([base[:, 4], np.abs(base[:, 5]), np.clip(base[:, 6], 0.01, 0.99)]))
+    else:
+        kw = dict(lnlike_bg=lnbg, density=c["density"])
+        cols.append(np.clip(base[:, 6], 0.01, 0.99)[:, None])
+    params = np.ascontiguousarray(np.column_stack(cols))
+    mid = {"bgfixed": native.MODEL_CONST_BGFIXED, "bggauss": native.MODEL_CONST_BGGAUSS,
+           "profile_bgdens": native.MODEL_PROFILE_BGDENS, "profile_bggauss": native.MODEL_PROFILE_BGGAUSS,
+           "profile_bgfixed": native.MODEL_PROFILE_BGFIXED}[model]
+    res = {}
+    for prec in ("f64", "f32acc64", "f32"):
+        cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=mid, centre=None if free else centre,
+                             precision=prec, **kw)
+        res[prec] = cat.loglike(params)
+        if prec != "f64":
+            assert cat.fast_level == 1, (model, prec)
+        cat.close()
+    # free centre: the tangent-plane offsets are differences of O(1) float32 products (relative error 6e-8 / r ~ 1e-4 per
+    # star near the centre), so the float32 geometry itself limits the agreement -- for the plain float32 kernels too
+    assert rel_err(res["f32acc64"], res["f64"]) < (1e-5 if free else 2e-6), model
+    assert rel_err(res["f32"], res["f64"]) < (1e-4 if free else 5e-5), model
+    if model == "bgfixed" and not free:
+        pm = c["pmember"].copy()
+        pm[7] = 1.0                                                     # a certain member: outside the float32 fast ranges
+        cat = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=mid, centre=centre, precision="f32acc64",
+                             lnlike_bg=lnbg, pmember=pm)
+        got = cat.loglike(params)
+        assert cat.fast_level == 0
+        ref = native.Catalog(ctx, c["ra"], c["dec"], c["v"], c["verr"], model=mid, centre=centre, lnlike_bg=lnbg, pmember=pm)
+        assert rel_err(got, ref.loglike(params)) < 2e-6
