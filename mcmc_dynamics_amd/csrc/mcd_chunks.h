@@ -44,8 +44,8 @@ struct ChunkPlan {
 // Chunk table of the shard [star_begin, star_begin + n) of a catalogue whose parameter sets (radial bins) are the
 // global star ranges bin_offsets[p] .. bin_offsets[p + 1]; a bin that straddles the shard edge contributes its local
 // part (the partial sums of the shards add up in the all-reduce).
-//   * nominal length = the odd multiple of 32 nearest to n n_wtiles / waves, at least 96, with waves = target_waves for
-//     >= 256 walkers (2/3 and 1/2 of it for 2-3 and 1 walker tiles)
+//   * nominal length = the odd multiple of 32 nearest to n n_wtiles / target_waves for >= 256 walkers, to
+//     1.25 n n_wtiles / 8000 below (one round of resident waves, guided tail included); at least 96
 //   * guided schedule (tail_split): workgroups are dispatched in chunk order, so the end of a large parameter set is
 //     cut into shorter chunks and the launch ends on short waves.  0 equal chunks; 1 = 85/10/5 % at len, len/2, len/4;
 //     2 = 70/15/10/5 % down to len/8; 3, 4 = guided self-scheduling, chunk = remaining work / (G x resident waves)
@@ -57,10 +57,13 @@ inline ChunkPlan plan_chunks(const std::vector<int64_t>& bin_offsets, int64_t st
     ChunkPlan plan;
     const int64_t n_psets = (int64_t)bin_offsets.size() - 1;
     const int64_t n_wtiles = (n_walkers + 63) / 64;
-    // Fewer, longer chunks when a workgroup's four waves are spread over several chunks (<= 128 walkers): measured best
-    // near 12288 / 8192 / 6144 waves per launch for >= 4 / 2-3 / 1 walker tiles (tools/chunk_len_probe.py).
-    const int64_t waves = std::max<int64_t>(1, n_wtiles >= 4 ? target_waves : (n_wtiles >= 2 ? target_waves * 2 / 3 : target_waves / 2));
-    int64_t len = (n * n_wtiles + waves - 1) / waves;
+    // >= 256 walkers: `target_waves` (12288 = 1.5 full-occupancy sets of 256 CUs x 4 SIMDs x 8 waves) full-length waves,
+    // i.e. ~1.7 rounds of resident waves once the guided tail is added.  <= 192 walkers (a workgroup's four waves are
+    // spread over several chunks): ONE round -- 8000 waves including the ~25 % extra chunks of the guided tail; 1.1 - 1.5
+    // rounds, where the last round runs nearly empty, cost 10 - 25 % (tools/chunk_len_probe.py).
+    int64_t len;
+    if (n_wtiles >= 4) len = (n * n_wtiles + target_waves - 1) / std::max<int64_t>(1, target_waves);
+    else len = (5 * n * n_wtiles / 4 + (target_waves * 2 / 3 - 192) - 1) / std::max<int64_t>(1, target_waves * 2 / 3 - 192);
     if (chunk_len > 0) {
         len = std::max<int64_t>(64, (chunk_len + 31) / 32 * 32);   // explicit nominal length (option "chunk_len", tuning)
     } else {

@@ -75,7 +75,7 @@ def test_guided_schedule_ends_on_short_chunks_and_equal_schedule_is_arithmetic()
     huge = em.plan_chunks([0, 8 << 20], 0, 8 << 20, 64, 1, 0)
     assert huge["len"] == (1 << 20) - 32 and huge["count"].max() == (1 << 20) - 32
     # fewer, longer chunks for <= 128 walkers; never a multiple of 64 stars
-    assert em.plan_chunks([0, 1000000], 0, 1000000, 128, 12288, 1)["len"] == 224
+    assert em.plan_chunks([0, 1000000], 0, 1000000, 128, 12288, 1)["len"] == 288
     assert em.plan_chunks([0, 1000000], 0, 1000000, 64, 12288, 1)["len"] == 160
     assert em.plan_chunks([0, 1250000], 0, 1250000, 256, 12288, 1)["len"] == 416
     assert em.plan_chunks([0, 5000], 0, 5000, 256, 12288, 1)["len"] == 96
