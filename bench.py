@@ -454,10 +454,20 @@ def main():
             uid = group.bcast_bytes(uid, src=0)
             ctx = None
             if len(uid) == native.UNIQUE_ID_BYTES:
-                try:
-                    ctx = native.Context(rank=rank, n_ranks=world, unique_id=uid, device=local_rank)
-                except native.NativeError as exc:
-                    err = str(exc)
+                # ncclCommInitRank under the same watchdog as the first all-reduce: a bootstrap that never completes must
+                # end in the marked line, not in a job that hangs until the driver's limit
+                box = {}
+
+                def init():
+                    try:
+                        box["ctx"] = native.Context(rank=rank, n_ranks=world, unique_id=uid, device=local_rank)
+                    except native.NativeError as exc:
+                        box["err"] = str(exc)
+                th = threading.Thread(target=init, daemon=True)
+                th.start()
+                th.join(COLLECTIVE_TIMEOUT_S)
+                ctx = box.get("ctx")
+                err = box.get("err", "" if ctx is not None else "ncclCommInitRank did not return within {0} s".format(COLLECTIVE_TIMEOUT_S))
             ok = int(group.allreduce(np.array([1 if ctx is not None else 0], dtype=np.int64), op="min")[0])
             errs = group.bcast_json(err, src=0) if ok == 0 else ""
         except HostGroupError as exc:

@@ -566,7 +566,11 @@ int make_slot(int device, DeviceSlot* slot) {
         return fail(MCD_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     slot->device = device;
     MCD_HIP(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
-    MCD_HIP(hipStreamCreateWithFlags(&slot->comm_stream, hipStreamNonBlocking));
+    // the communication stream gets the highest priority: its one small all-reduce kernel per step should take the next
+    // free CU slots while the following step's main kernel (thousands of queued workgroups) is being dispatched
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
+    MCD_HIP(hipStreamCreateWithPriority(&slot->comm_stream, hipStreamNonBlocking, prio_greatest));
     return MCD_OK;
 }
 
