@@ -27,7 +27,8 @@ int main(int argc, char** argv) {
         (any_fn)mcd_membership, (any_fn)mcd_loglike_per_star, (any_fn)mcd_kde_background,
         (any_fn)mcd_last_error, (any_fn)mcd_abi_version, (any_fn)mcd_last_kernel_ms,
         (any_fn)mcd_last_device_ms, (any_fn)mcd_set_option, (any_fn)mcd_timing_collect,
-        (any_fn)mcd_rerun_count, (any_fn)mcd_last_fast_level, (any_fn)mcd_last_launch_info};
+        (any_fn)mcd_rerun_count, (any_fn)mcd_last_fast_level, (any_fn)mcd_last_launch_info,
+        (any_fn)mcd_ctx_comm_info, (any_fn)mcd_stretch_move};
     size_t i;
     double out[3] = {0.0, 0.0, 0.0};
     for (i = 0; i < sizeof table / sizeof table[0]; ++i) CHECK(table[i] != NULL);
@@ -39,6 +40,8 @@ int main(int argc, char** argv) {
     CHECK(mcd_catalog_create(NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_kde_background(NULL, 1, out, 1, out, out, 0.0, out, NULL) != MCD_OK);
     CHECK(mcd_last_fast_level(NULL) == -1);
+    CHECK(mcd_ctx_comm_info(NULL, NULL, NULL, NULL) != MCD_OK);
+    CHECK(mcd_stretch_move(NULL, NULL, 1, out, out, NULL, out, out, NULL, NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_catalog_destroy(NULL) == MCD_OK);
     CHECK(mcd_ctx_destroy(NULL) == MCD_OK);
     printf("abi %d: %d entry points link from C\n", mcd_abi_version(), (int)(sizeof table / sizeof table[0]));
@@ -69,6 +72,29 @@ int main(int argc, char** argv) {
             }
         for (w = 0; w < 2; ++w) CHECK(fabs(got[w] - want[w]) < 1e-13);
         CHECK(mcd_loglike_batch(cat, 2, 5, &rows[0][0], got) != MCD_OK);      /* wrong column count */
+        {
+            /* one stretch-move step of two walkers driven from C: identity column map, no bounds; with z = 1 the proposal
+             * is the walker itself, so the log-probability is unchanged and (thr = -1 < 0) the "move" is accepted */
+            const double inf = 1.0 / 0.0;
+            int32_t src[4] = {0, 1, 2, 3}, order[2] = {0, 1}, pick[2] = {0, 0};
+            double cst[4] = {0, 0, 0, 0}, fac[4] = {1, 1, 1, 1}, lo[4], hi[4], zz[2] = {1.0, 1.0}, thr[2] = {-1.0, -1.0};
+            double pos[2][4] = {{0.25, 3.0, 0.0, 0.0}, {0.0, 7.5, 0.0, 0.0}}, lnp[2], chain[8], lnpc[2];
+            int64_t acc[2] = {0, 0};
+            int comm_size = -1, comm_rank = 0, version = -1;
+            mcd_stretch_desc sd;
+            for (w = 0; w < 4; ++w) { lo[w] = -inf; hi[w] = inf; }
+            lo[1] = 0.0;
+            memset(&sd, 0, sizeof sd);
+            sd.n_walkers = 2; sd.n_dim = 4; sd.k = 4; sd.col_source = src; sd.col_const = cst; sd.col_factor = fac;
+            sd.lo = lo; sd.hi = hi; sd.fixed_ok = 1;
+            lnp[0] = got[0]; lnp[1] = got[1];
+            CHECK(mcd_stretch_move(cat, &sd, 1, &pos[0][0], lnp, order, zz, thr, pick, chain, lnpc, acc) == MCD_OK);
+            CHECK(acc[0] == 1 && acc[1] == 1 && fabs(lnpc[0] - want[0]) < 1e-13 && fabs(lnpc[1] - want[1]) < 1e-13);
+            CHECK(chain[1] == 3.0 && chain[5] == 7.5);
+            order[1] = 7;                                                       /* an index outside the ensemble */
+            CHECK(mcd_stretch_move(cat, &sd, 1, &pos[0][0], lnp, order, zz, thr, pick, chain, lnpc, acc) == MCD_ERR_INVALID);
+            CHECK(mcd_ctx_comm_info(ctx, &comm_size, &comm_rank, &version) == MCD_OK && comm_size == 0 && comm_rank == -1);
+        }
         CHECK(mcd_catalog_destroy(cat) == MCD_OK && mcd_ctx_destroy(ctx) == MCD_OK);
         printf("gpu closed form ok: %.15g %.15g\n", got[0], got[1]);
     }

@@ -9,7 +9,7 @@ import emul_helper as emul
 from conftest import rel_err
 
 CENTRE = (56.345, -26.675)
-MODELS = {0: 4, 1: 4, 2: 7, 3: 6, 4: 9, 5: 7}          # model id -> K (fixed centre)
+MODELS = {0: 4, 1: 4, 2: 7, 3: 6, 4: 9, 5: 7, 6: 6}    # model id -> K (fixed centre)
 
 
 def random_case(rng, model, n=300, w=6):
@@ -90,5 +90,12 @@ def test_guard_refuses_what_the_fast_paths_cannot_represent():
     a0 = p3.copy()
     a0[0, 2] = 0.0
     assert not emul.fast_guard(cat3, a0, 3, CENTRE)                       # a = 0: plain path reproduces the reference's limit
-    assert not emul.fast_guard(cat1, p1, 1, CENTRE, f32=True)             # f32 mixtures always plain
+    # float32 fast mixtures: refused while a certain member (pmember == 1) is in the catalogue, admitted for tame columns
+    assert cat1["pmember"].max() == 1.0 and not emul.fast_guard(cat1, p1, 1, CENTRE, f32=True)
+    tame = dict(cat1, pmember=np.clip(cat1["pmember"], 0.0, 0.99), v=np.clip(cat1["v"], -100, 100), verr=np.full(len(cat1["v"]), 2.0),
+                lnlike_bg=np.clip(cat1["lnlike_bg"], -8.0, 0.0))
+    pt = p1.copy()
+    pt[:, 0], pt[:, 1], pt[:, 2], pt[:, 3] = 1.0, 9.0, 2.0, -1.0
+    assert emul.fast_guard(tame, pt, 1, CENTRE, f32=True)
+    assert not emul.fast_guard(dict(tame, lnlike_bg=np.full(len(cat1["v"]), -70.0)), pt, 1, CENTRE, f32=True)   # y would leave float range
     assert emul.fast_guard(cat, params, 0, CENTRE, f32=True) in (True, False)
