@@ -65,7 +65,14 @@ std::mutex g_rccl_mutex;
 int load_rccl() {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);          // contexts may be created from several host threads
     if (g_rccl.handle) return MCD_OK;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // MCD_RCCL_LIBRARY: an explicit library path.  Used by the tests to substitute tests/fake_rccl (a host-staged
+    // stand-in) so that one GPU can run the multi-rank / multi-device call sequences with real shards and kernels.
+    void* h = nullptr;
+    if (const char* forced = std::getenv("MCD_RCCL_LIBRARY")) {
+        h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return fail(MCD_ERR_RCCL, std::string("cannot load MCD_RCCL_LIBRARY: ") + dlerror());
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(MCD_ERR_RCCL, std::string("cannot load librccl.so: ") + dlerror());
@@ -586,7 +593,14 @@ int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out) {
     if (!out || n_dev <= 0) return fail(MCD_ERR_INVALID, "mcd_ctx_create: bad arguments");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(MCD_ERR_NO_DEVICE, "no HIP device visible");
-    if (n_dev > count) return fail(MCD_ERR_NO_DEVICE, "more devices requested than visible");
+    // MCD_ALLOW_SHARED_DEVICE=1 (testing aid, with MCD_RCCL_LIBRARY): several shards may sit on the same device, each with
+    // its own streams -- real RCCL refuses that, the stand-in of tests/fake_rccl does not
+    const char* shared_dev = std::getenv("MCD_ALLOW_SHARED_DEVICE");
+    const bool allow_shared = shared_dev && shared_dev[0] == '1' && dev_ids != nullptr;
+    if (n_dev > count && !allow_shared) return fail(MCD_ERR_NO_DEVICE, "more devices requested than visible");
+    if (dev_ids)
+        for (int i = 0; i < n_dev; ++i)
+            if (dev_ids[i] < 0 || dev_ids[i] >= count) return fail(MCD_ERR_NO_DEVICE, "device index out of range");
     std::unique_ptr<mcd_ctx, int (*)(mcd_ctx*)> ctx(new (std::nothrow) mcd_ctx(), &mcd_ctx_destroy);   // streams / communicators released on every error path
     if (!ctx) return fail(MCD_ERR_INVALID, "out of memory");
     ctx->slots.resize(n_dev);
