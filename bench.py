@@ -189,7 +189,7 @@ def mapped_libraries():
             for line in f:
                 path = line.split()[-1]
                 base = os.path.basename(path)
-                for key in ("libamdhip64", "librccl", "libmcd_hip", "libhsa-runtime64"):
+                for key in ("libamdhip64", "librccl", "libfake_rccl", "libmcd_hip", "libhsa-runtime64"):
                     if base.startswith(key):
                         found[key] = path
     except OSError:
@@ -659,7 +659,9 @@ def main():
         "collective": None if world == 1 else {
             "kind": "ncclAllReduce(sum, f64, count = {0}) per step; pipelined steps run it on a second HIP stream".format(n_walkers * n_bins),
             "comm_size": comm["size"], "comm_rank_of_rank0": comm["rank"], "rccl_version": comm["rccl_version"],
-            "first_allreduce_watchdog_s": COLLECTIVE_TIMEOUT_S},
+            "first_allreduce_watchdog_s": COLLECTIVE_TIMEOUT_S,
+            # MCD_RCCL_LIBRARY substitutes the collective library (tests/fake_rccl on a single-GPU box): flow check only
+            "library_override": os.environ.get("MCD_RCCL_LIBRARY")},
         "libraries": mapped_libraries(),
         "c4_strong": strong_rec,
     }
