@@ -87,6 +87,15 @@ def parse_args():
 
 
 def build_catalog(native, ctx, synthetic, cat, model, precision="f64", bin_offsets=None):
+    g = _build_catalog(native, ctx, synthetic, cat, model, precision, bin_offsets)
+    # tuning aid (tools/ab_option.sh): MCD_BENCH_OPTIONS="key=value,..." goes to mcd_set_option; echoed in the bench line
+    for item in filter(None, os.environ.get("MCD_BENCH_OPTIONS", "").split(",")):
+        key, value = item.split("=")
+        g.set_option(key.strip(), int(value))
+    return g
+
+
+def _build_catalog(native, ctx, synthetic, cat, model, precision, bin_offsets):
     centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
     if model == "const":
         return native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST, centre=centre,
@@ -663,6 +672,7 @@ def main():
             # MCD_RCCL_LIBRARY substitutes the collective library (tests/fake_rccl on a single-GPU box): flow check only
             "library_override": os.environ.get("MCD_RCCL_LIBRARY")},
         "libraries": mapped_libraries(),
+        "option_overrides": os.environ.get("MCD_BENCH_OPTIONS") or None,
         "c4_strong": strong_rec,
     }
     out["dtype"] = {"f64": "f64", "f32": "f32", "f32acc64": "f32 terms, f64 accumulation"}[args.precision]

@@ -228,6 +228,10 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *   "spin_us"       microseconds mcd_sync / fetch / batch poll the stream (hipStreamQuery) before they fall back to the
  *                      blocking hipStreamSynchronize, whose interrupt wake-up adds 50 - 500 us of jitter to waits longer
  *                      than a fraction of a millisecond (default 20000; 0: always block)
+ *   "prefetch"      software prefetch of the star records of the next loop iteration: -1 (default) on for devices whose
+ *                      share of the catalogue is at least 8 MiB of records (it hides the memory latency there, +1 % at
+ *                      256 walkers to +45 % at 64 on 1e6 stars) and off below (the records stay in the caches; the
+ *                      prefetch costs ~5 % there); 0 off, 1 on.  Results do not depend on it.
  *   "target_waves"  number of waves the chunking aims for per device (default 12288)
  *   "chunk_len"     explicit nominal chunk length in stars (rounded up to a multiple of 32; 0, the default: derived from
  *                      "target_waves"); tuning aid

@@ -183,6 +183,7 @@ struct mcd_catalog {
     int tail_split = 1;                // guided chunk schedule (shorter chunks at the end of a launch)
     int64_t target_waves = 12288;
     int64_t chunk_len = 0;             // option "chunk_len": explicit nominal chunk length (0: from target_waves)
+    int prefetch = -1;                 // option "prefetch": -1 by record volume (>= 8 MiB per device), 0 off, 1 on
     // state of the last evaluation
     int64_t cur_walkers = 0;
     double last_kernel_ms = -1.0, last_device_ms = -1.0;
@@ -404,6 +405,9 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
             w.buf = 0;
         }
         shape.chunk_general = w.d_chunk_general;
+        // records beyond what the caches hold between two passes: prefetch the next loop iteration's records (mcd_math.h)
+        shape.prefetch = cat->prefetch >= 0 ? cat->prefetch != 0
+                                            : (size_t)sh.n * (size_t)mcd::record_bytes(cat->model, cat->free_centre, cat->precision) >= ((size_t)8 << 20);
         shape.rerun_flag = coll ? nullptr : out_buf + n_out;
         w.launch_tag = coll ? 0.0 : (double)(++cat->launch_seq);
         shape.launch_tag = w.launch_tag;
@@ -774,8 +778,10 @@ static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::uni
         MCD_HIP(hipEventCreate(&sh.ev_k0));
         MCD_HIP(hipEventCreate(&sh.ev_k1));
         MCD_HIP(hipEventCreate(&sh.ev_end));
-        MCD_HIP(hipMalloc(&sh.records, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256)));  // slack for wide scalar loads
-        MCD_HIP(hipMemsetAsync(sh.records, 0, std::max<size_t>(64, (size_t)sh.n * rec_bytes + 256), slot.stream));
+        // slack: wide scalar loads and the software prefetch of the following loop iterations (mcd_math.h: RecordPrefetch)
+        // read up to 1.5 KiB past a chunk's last record
+        MCD_HIP(hipMalloc(&sh.records, (size_t)sh.n * rec_bytes + 2048));
+        MCD_HIP(hipMemsetAsync(sh.records, 0, (size_t)sh.n * rec_bytes + 2048, slot.stream));
         if (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY) {
             const std::vector<double> sums = mcd::pset_background_sums(d->lnlike_bg, cat->bin_offsets, sh.star_begin, sh.n);
             MCD_HIP(hipMalloc(&sh.d_pset_const, sums.size() * sizeof(double)));
@@ -1011,6 +1017,11 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     if (!std::strcmp(key, "zero_copy")) { cat->zero_copy = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "prefetch")) {
+        if (value < -1 || value > 1) return fail(MCD_ERR_INVALID, "prefetch: -1 (by record volume, default), 0 (off) or 1 (on)");
+        cat->prefetch = (int)value;
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "spin_us")) {
         if (value < 0) return fail(MCD_ERR_INVALID, "spin_us must be >= 0");
         cat->spin_us = value;

@@ -17,6 +17,7 @@ struct LaunchShape {
     int64_t n_records = 0;
     const uint8_t* chunk_general = nullptr;   // fast == 2: chunks that must take the general fast form (hold a star that
                                               // rules out the narrow-range variant, mcd_guard.h: narrow_exception); may be null
+    bool prefetch = false;          // software prefetch of the next iteration's records (catalogues beyond the caches)
     double* rerun_flag = nullptr;   // device word the fast mixture kernels set to `launch_tag` in the denormal regime
     double launch_tag = 0.0;
 };

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
                                                           int n_wtiles, int64_t n_walkers, int64_t n_chunks,
                                                           int uniform_len, int64_t n_records,
                                                           double* __restrict__ rerun_flag, double launch_tag,
-                                                          const uint8_t* __restrict__ chunk_general) {
+                                                          const uint8_t* __restrict__ chunk_general, int prefetch) {
     constexpr int ND = record_doubles(MODEL, FREE);
     // fast mixtures: the 2^(j/1024) table of exp_tab lives in LDS (8 KiB per workgroup), four entries copied per thread
     constexpr bool kUsesExpTab = FAST && bg_kind(MODEL) != BG_NONE && sizeof(T) == 8;
@@ -183,17 +183,18 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
     WalkerConsts<T> w;
     w.load(wp);                                   // unused constants are dead code for a given MODEL
 
-    // wave-uniform record pointer: the reads inside chunk_loglike become scalar loads
+    // wave-uniform record pointer in the constant address space: the reads inside chunk_loglike are scalar loads
+    const RecPtr<T> chunk_recs = (RecPtr<T>)(recs + ch.begin * ND);
     bool denormal;
     double result;
     if constexpr (FAST == 2) {
         // a chunk that holds a star outside the narrow-range domain (certain member, extreme background, ...) takes the
         // general fast form; the flag is wave-uniform (one scalar byte load), so this is a scalar branch
         const bool general = chunk_general != nullptr && chunk_general[chunk_id] != 0;
-        if (general) result = chunk_loglike<MODEL, FREE, T, A, 1>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
-        else result = chunk_loglike<MODEL, FREE, T, A, 2>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
+        if (general) result = chunk_loglike<MODEL, FREE, T, A, 1>(chunk_recs, ch.count, w, denormal, exptab_lds, prefetch != 0);
+        else result = chunk_loglike<MODEL, FREE, T, A, 2>(chunk_recs, ch.count, w, denormal, exptab_lds, prefetch != 0);
     } else {
-        result = chunk_loglike<MODEL, FREE, T, A, FAST>(recs + ch.begin * ND, ch.count, w, denormal, exptab_lds);
+        result = chunk_loglike<MODEL, FREE, T, A, FAST>(chunk_recs, ch.count, w, denormal, exptab_lds, prefetch != 0);
     }
     // denormal regime of the reference's log-sum-exp met: tell the host to re-evaluate this batch with the plain kernels
     // One device: the flag word gets this launch's tag.  Several ranks / devices (rerun_flag == nullptr): the partial sum
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void per_star_kernel(const T* __restrict__ 
     WalkerConsts<T> w;
     w.load(wp);
     T lc, lb, m;
-    star_components<MODEL, FREE, T>(recs + i * ND, w, lc, lb, m);
+    star_components<MODEL, FREE, T>((RecPtr<T>)(recs + i * ND), w, lc, lb, m);
     if (mode == 1) { out[i] = (double)mixture_lnl(lc, lb, m); return; }
     const T shift = is_profile(MODEL) ? max_(lc, lb) : T(0);
     const T ec = m * exp_(lc - shift), eb = (T(1) - m) * exp_(lb - shift);
@@ -280,14 +281,14 @@ __global__ __launch_bounds__(kBlock) void per_star_kernel(const T* __restrict__ 
 template <int MODEL, bool FREE, class T, class A, int FAST>
 hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, int64_t n_chunks, const void* wpar,
                       double* partials, int64_t n_walkers, int uniform_len, int64_t n_records, double* rerun_flag,
-                      double launch_tag, const uint8_t* chunk_general) {
+                      double launch_tag, const uint8_t* chunk_general, int prefetch) {
     const int n_wtiles = (int)((n_walkers + kWave - 1) / kWave);
     const int64_t n_tasks = n_chunks * n_wtiles;
     const int64_t grid = main_grid(n_chunks, n_walkers);   // > 256 walkers: XCD-aware grouping, see loglike_kernel
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST>), dim3((unsigned)grid), dim3(kBlock), 0, s,
                        (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,
-                       uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+                       uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
     return hipGetLastError();
 }
 
@@ -299,27 +300,28 @@ hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* re
     double* const rerun_flag = sh.rerun_flag;
     const double launch_tag = sh.launch_tag;
     const uint8_t* const chunk_general = sh.chunk_general;
+    const int prefetch = sh.prefetch ? 1 : 0;
     switch (sh.precision) {
         case 0:
             if constexpr (bg_kind(MODEL) != BG_NONE) {
                 if (sh.fast == 2)
                     return launch_one<MODEL, FREE, double, double, 2>(s, records, chunks, n_chunks, wpar, partials,
-                                                                      n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+                                                                      n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
             }
             if (sh.fast)
                 return launch_one<MODEL, FREE, double, double, 1>(s, records, chunks, n_chunks, wpar, partials,
-                                                                  n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
-            return launch_one<MODEL, FREE, double, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+                                                                  n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
+            return launch_one<MODEL, FREE, double, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
         case 1:      // float32 terms and sums: fast formulations for every model when the f32 guard admits them (mcd_guard.h)
             if (sh.fast)
                 return launch_one<MODEL, FREE, float, float, 1>(s, records, chunks, n_chunks, wpar, partials, n_walkers,
-                                                                uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
-            return launch_one<MODEL, FREE, float, float, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+                                                                uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
+            return launch_one<MODEL, FREE, float, float, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
         case 2:      // float32 terms, float64 accumulation
             if (sh.fast)
                 return launch_one<MODEL, FREE, float, double, 1>(s, records, chunks, n_chunks, wpar, partials, n_walkers,
-                                                                 uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
-            return launch_one<MODEL, FREE, float, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+                                                                 uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
+            return launch_one<MODEL, FREE, float, double, 0>(s, records, chunks, n_chunks, wpar, partials, n_walkers, uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
     }
     return hipErrorInvalidValue;
 }

@@ -24,6 +24,17 @@
 #else
 #define MCD_HD inline
 #endif
+// Star records are read through the CONSTANT address space on the device: a wave-uniform load from it is a scalar load
+// (s_load_dwordxN) by construction.  From the global address space the compiler emits scalar loads only while it can
+// prove that nothing in the kernel may have written the memory; an inline asm that takes the record pointer (the
+// software prefetch below) ends that proof and the record reads silently become per-lane global_load instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MCD_CONST_AS __attribute__((address_space(4)))
+#else
+#define MCD_CONST_AS
+#endif
+namespace mcd { template <class T> using RecPtr = const T MCD_CONST_AS*; }
+
 // An empty volatile asm keeps the compiler from turning a small wave-uniform `if` into per-lane selects (v_cndmask on
 // every iteration): the block stays behind a scalar branch.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -686,6 +697,7 @@ struct BgFixedAccF {
     MCD_HD void rescale_density() { l.rescale(); lden.rescale(); }
     MCD_HD double finish() { return l.value(); }
     MCD_HD double finish_density() { return l.value() - lden.value(); }
+    MCD_HD A value_for_anchor() const { return l.p; }
 };
 // BG_GAUSS:  y = rho g + f gb e^{-delta} (or mirrored), as BgGaussAcc
 template <class A>
@@ -708,6 +720,7 @@ struct BgGaussAccF {
     MCD_HD double finish(int64_t count) {
         return fma_(-(double)count, kHalfLn2Pi, -0.5 * (double)sum_min) + (ly.value() - lden.value());
     }
+    MCD_HD A value_for_anchor() const { return ly.p; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -731,6 +744,47 @@ struct KdeLane {
         // one-constant range reduction: relative error 8e-17 |u| in a term that is e^u <= 1 of a sum >= 1
         const double er = exp_tab<false>(u, k, exptab);
         sum += ldexp_(er, k);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Software prefetch of the star records the NEXT loop iteration reads, through the VECTOR memory path: lane l < LINES
+// loads one word of the l-th 64-byte line, which pulls the lines into L2; the scalar loads of the next iteration then
+// find them there.  (A scalar-load prefetch was tried first: the scalar cache serves a wave's requests in order, so the
+// iteration's own loads queued behind the prefetch misses -- 7 - 18 % slower, gpurun_out/ab_prefetch.txt.)  The loaded
+// word is kept alive until retire(), so the compiler's own s_waitcnt vmcnt covers it.  Reads up to 1.5 KiB past the
+// chunk: the record array is allocated with that slack.  Measured on C3 (gpurun_out/ab_prefetch*.txt): 256 walkers
+// 202.7 -> 200.1 us, 128 walkers 117.2 -> 107.4 us, 64 walkers 89.5 -> 61.5 us; with 256 walkers three of a chunk's four
+// waves find their records fetched by the first, with fewer walkers every wave waits for memory on its own (VALUBusy
+// 85 % / 67 % without the prefetch, tools/sq_w128.sh).
+#ifndef MCD_PREFETCH_DISTANCE
+#define MCD_PREFETCH_DISTANCE 1          // loop iterations ahead
+#endif
+template <int BYTES>
+struct RecordPrefetch {
+    static constexpr int kLines = (BYTES + 63) / 64 > 8 ? 8 : (BYTES + 63) / 64;
+    uint32_t t;
+    // `enabled` is wave-uniform (a launch parameter): catalogues that fit the caches gain nothing from the prefetch and
+    // pay ~5 % for its bookkeeping (C2: 17.0 vs 16.1 us per step), so the library switches it on from 8 MiB of records up
+    template <class P>
+    MCD_HD void issue(P next, bool enabled) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MCD_NO_PREFETCH)
+        const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        typedef const uint32_t __attribute__((address_space(1)))* global_word_ptr;
+        t = 0;
+        if (enabled && lane < (unsigned)kLines) t = *(global_word_ptr)((uint64_t)next + lane * 64u);
+#else
+        (void)next;
+        (void)enabled;
+        t = 0;
+#endif
+    }
+    MCD_HD void retire(double anchor) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MCD_NO_PREFETCH)
+        asm volatile("" :: "v"(t), "v"(anchor));
+#else
+        (void)anchor;
+#endif
     }
 };
 
@@ -761,7 +815,7 @@ template <class T> MCD_HD T sqrt_(T x) {
 //   PROFILE (model.py:93-180):    v_los = v_sys + 2 r_peak (v_maxx dy - v_maxy dx) / (r_peak^2 + r^2)
 //                                 sigma_los^2 = sigma_max^2 a / sqrt(a^2 + r^2)           (all lengths in arcsec)
 template <int MODEL, class T, bool FREE, bool FASTMATH = false>
-MCD_HD void star_d_n(const T* __restrict__ r, const WalkerConsts<T>& w, T& d, T& n) {
+MCD_HD void star_d_n(RecPtr<T> r, const WalkerConsts<T>& w, T& d, T& n) {
     if constexpr (!is_profile(MODEL)) {
         if (FREE) d = free_centre_residual<FASTMATH>(r[2], r[3], r[4], w.sac, w.cac, w.sdc, w.cdc, w.vx, w.vy, r[0] - w.vsys);
         else d = fma_(-w.vx, r[2], fma_(w.vy, r[3], r[0] - w.vsys));
@@ -798,8 +852,8 @@ MCD_HD constexpr bool exp_table_is_sqrt2_scaled(int model) { return model == MOD
 // narrow-range products of BgFixedAcc::add (MODEL_BGFIXED, MODEL_PROFILE_BGDENS) / BgGaussAcc::add (MODEL_BGGAUSS,
 // MODEL_PROFILE_BGGAUSS); for the models without background the same as 1.
 template <int MODEL, bool FREE, class T, class A, int FAST>
-MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerConsts<T>& w, bool& denormal,
-                            const double* __restrict__ exptab) {
+MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bool& denormal,
+                            const double* __restrict__ exptab, bool prefetch = false) {
     constexpr int ND = record_doubles(MODEL, FREE);
     denormal = false;
     constexpr int XB = geometry_doubles(MODEL, FREE);      // first background slot of a record
@@ -811,16 +865,19 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         auto run4 = [&](auto& acc, auto&& one, auto&& rescale) {
             const int n4 = count >> 2;
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                RecordPrefetch<4 * ND * 4> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) one(r + j * ND);
                 rescale();
+                pf.retire((double)acc.value_for_anchor());
             }
             for (int j = n4 * 4; j < count; ++j, r += ND) { one(r); rescale(); }
         };
         if constexpr (BG == BG_GAUSS) {
             BgGaussAccF<A> acc;
             acc.init();
-            run4(acc, [&](const T* rr) {
+            run4(acc, [&](RecPtr<T> rr) {
                 T d, n;
                 star_d_n<MODEL, T, FREE, true>(rr, w, d, n);
                 acc.add(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb);
@@ -829,7 +886,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         } else if constexpr (BG == BG_FIXED) {
             BgFixedAccF<A> acc;
             acc.init();
-            run4(acc, [&](const T* rr) {
+            run4(acc, [&](RecPtr<T> rr) {
                 T d, n;
                 star_d_n<MODEL, T, FREE, true>(rr, w, d, n);
                 acc.add(d, n, rr[XB + 2], rr[XB + 3]);
@@ -838,7 +895,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         } else {
             BgFixedAccF<A> acc;
             acc.init();
-            run4(acc, [&](const T* rr) {
+            run4(acc, [&](RecPtr<T> rr) {
                 T d, n;
                 star_d_n<MODEL, T, FREE, true>(rr, w, d, n);
                 acc.add_density(d, n, rr[XB + 2], w.fb, rr[XB + 1]);
@@ -856,6 +913,8 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         constexpr bool TREE16 = MODEL == MODEL_CONST && !FREE;
         const int n16 = TREE16 ? count >> 4 : 0;
         for (int g = 0; g < n16; ++g, r += 16 * ND) {
+            RecordPrefetch<16 * ND * 4> pf;
+            pf.issue(r + MCD_PREFETCH_DISTANCE * 16 * ND, prefetch);
             float qq[16], nn[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -865,6 +924,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc.add4(qq + 4 * t, nn + 4 * t);
+            pf.retire((double)acc.p);
         }
         const int done = n16 << 4;
         const int n4 = (count - done) >> 2;
@@ -893,6 +953,8 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         constexpr bool TREE16 = MODEL == MODEL_CONST && !FREE;
         const int n16 = TREE16 ? count >> 4 : 0;
         for (int g = 0; g < n16; ++g, r += 16 * ND) {
+            RecordPrefetch<16 * ND * 8> pf;
+            pf.issue(r + MCD_PREFETCH_DISTANCE * 16 * ND, prefetch);
             double qq[16], nn[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -901,9 +963,12 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 qq[j] = d * d;
             }
             acc.add16(qq, nn);
+            pf.retire(acc.q);
         }
         const int n8 = TREE16 ? (count >> 3) & 1 : count >> 3;
         for (int g = 0; g < n8; ++g, r += 8 * ND) {
+            RecordPrefetch<8 * ND * 8> pf;
+            pf.issue(r + MCD_PREFETCH_DISTANCE * 8 * ND, prefetch);
             double qq[8], nn[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -912,6 +977,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
                 qq[j] = d * d;
             }
             acc.add8(qq, nn);
+            pf.retire(acc.q);
         }
         for (int j = count & ~7; j < count; ++j, r += ND) {
             double d, n;
@@ -940,10 +1006,10 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         const double s2x = kScale * (double)w.s2;
         BgFixedAcc acc;
         acc.init();
-        auto four = [&](const double* __restrict__ r4) {
+        auto four = [&](RecPtr<double> r4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const double* rr = r4 + j * ND;
+                RecPtr<double> rr = r4 + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
                 if constexpr (HALVED) n = fma_(kScale, rr[1], s2x);
@@ -954,12 +1020,21 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         if constexpr (NARROW) {
             // eight raw factors per rescale: every second 4-star group (one scalar record-load batch each)
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                RecordPrefetch<4 * ND * 8> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
                 four(r);
+                pf.retire(acc.l.p);
                 if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_narrow(); }    // wave-uniform: a scalar branch, not a select
             }
             if (n4 & 1) acc.rescale_narrow();
         } else {
-            for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale(); }
+            for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                RecordPrefetch<4 * ND * 8> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                four(r);
+                pf.retire(acc.l.p);
+                acc.rescale();
+            }
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
@@ -974,10 +1049,10 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         constexpr bool NARROW = FAST == 2;          // f_back >= 2^-20 bounds every mixture value from below (mcd_guard.h)
         BgFixedAcc acc;
         acc.init();
-        auto four = [&](const double* __restrict__ r4) {
+        auto four = [&](RecPtr<double> r4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const double* rr = r4 + j * ND;
+                RecPtr<double> rr = r4 + j * ND;
                 double d, n;
                 star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
                 acc.add_density<NARROW>(d, n, rr[XB + 2], w.fb, rr[XB + 1], exptab);
@@ -986,12 +1061,21 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         const int n4 = count >> 2;
         if constexpr (NARROW) {
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                RecordPrefetch<4 * ND * 8> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
                 four(r);
+                pf.retire(acc.l.p);
                 if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_density_narrow(); }    // wave-uniform: a scalar branch, not a select
             }
             if (n4 & 1) acc.rescale_density_narrow();
         } else {
-            for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale_density(); }
+            for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                RecordPrefetch<4 * ND * 8> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                four(r);
+                pf.retire(acc.l.p);
+                acc.rescale_density();
+            }
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
@@ -1010,25 +1094,34 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
         const double s2x = kScale * (double)w.s2, sb2x = kScale * (double)w.sb2;
         BgGaussAcc acc;
         acc.init();
-        auto one = [&](const double* __restrict__ rr) {
+        auto one = [&](RecPtr<double> rr) {
             double d, n;
             star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
             if constexpr (HALVED) acc.add<true, NARROW>(d, fma_(kScale, rr[1], s2x), rr[0] - w.vb, fma_(kScale, rr[1], sb2x), rr[XB], w.fb, exptab);
             else acc.add<false, NARROW>(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb, exptab);
         };
-        auto four = [&](const double* __restrict__ r4) {
+        auto four = [&](RecPtr<double> r4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) one(r4 + j * ND);
         };
         const int n4 = count >> 2;
         if constexpr (NARROW) {
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                RecordPrefetch<4 * ND * 8> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
                 four(r);
+                pf.retire(acc.ly.p);
                 if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_narrow(); }    // wave-uniform: a scalar branch, not a select
             }
             if (n4 & 1) acc.rescale_narrow();
         } else {
-            for (int g = 0; g < n4; ++g, r += 4 * ND) { four(r); acc.rescale(); }
+            for (int g = 0; g < n4; ++g, r += 4 * ND) {
+                RecordPrefetch<4 * ND * 8> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                four(r);
+                pf.retire(acc.ly.p);
+                acc.rescale();
+            }
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             one(r);
@@ -1067,7 +1160,7 @@ MCD_HD double chunk_loglike(const T* __restrict__ r, int count, const WalkerCons
 
 // Per-star log-likelihood pieces for the membership / no_sum outputs: cluster lnL, background lnL, prior m.
 template <int MODEL, bool FREE, class T>
-MCD_HD void star_components(const T* __restrict__ r, const WalkerConsts<T>& w, T& lc, T& lb, T& m) {
+MCD_HD void star_components(RecPtr<T> r, const WalkerConsts<T>& w, T& lc, T& lb, T& m) {
     constexpr int XB = geometry_doubles(MODEL, FREE);
     constexpr int BG = bg_kind(MODEL);
     T d, n;

@@ -660,9 +660,9 @@ def test_lifetime_order_is_safe(native):
     ctx2.close()
 
 
-def _realistic_case(rng):
+def _realistic_case(rng, n=None):
     """Random catalogue in the ranges of real data (what oracle/crosscheck_reference.py feeds the reference itself)."""
-    n = int(rng.integers(5, 3000))
+    n = int(rng.integers(5, 3000)) if n is None else n
     scale_v = 10.0 ** rng.uniform(0, 2.5)
     sep = np.maximum(np.abs(rng.normal(0, 2.0 / 60.0, n)), 1e-4)
     th = rng.uniform(-np.pi, np.pi, n)
@@ -738,3 +738,43 @@ def test_random_realistic_catalogues_against_the_oracle(native, ctx, model):
         ok = np.isfinite(want)
         assert np.max(np.abs(got[ok] - want[ok]) / np.maximum(np.abs(want[ok]), n), initial=0.0) < 1e-12, (trial, got, want)
     assert families <= {0, 1, 2} and (model == 0 or len(families) >= 1)
+
+
+@pytest.mark.parametrize("model,precision", [(0, "f64"), (1, "f64"), (2, "f64"), (5, "f64"), (0, "f32"), (1, "f32")])
+def test_record_prefetch_does_not_change_results(native, ctx, model, precision):
+    """Option "prefetch" (mcd_math.h: RecordPrefetch) only touches memory the loop reads one iteration later: the sums
+    are bitwise the same with it on and off, on ragged chunk lengths, and the last chunk's look-ahead past the end of
+    the record array stays inside the allocation's slack (a fault there would kill this test)."""
+    from oracle import lnprob_numpy as oracle
+    rng = np.random.default_rng(8100 + model)
+    for n in (1, 37, 4099, 70001):
+        cat, sv = _realistic_case(rng, n=n)
+        w = 9
+        cols = [rng.normal(0, sv, w), sv * 10.0 ** rng.uniform(-0.5, 0.5, w), rng.normal(0, sv, w), rng.normal(0, sv, w)]
+        if model == 2:
+            cols += [rng.normal(0, sv, w), sv * 10.0 ** rng.uniform(-0.3, 0.6, w), rng.random(w)]
+        if model == 5:
+            cols = cols[:2] + [10.0 ** rng.uniform(0, 2, w)] + cols[2:] + [10.0 ** rng.uniform(0, 2, w), rng.random(w)]
+        params = np.stack(cols, axis=1)
+        lnbg = oracle.gaussian_background(cat["v"], cat["verr"], 0.0, 3 * sv)
+        kw = {}
+        if model == 1:
+            kw = dict(lnlike_bg=lnbg, pmember=cat["pmember"])
+        elif model == 2:
+            kw = dict(density=cat["density"])
+        elif model == 5:
+            kw = dict(lnlike_bg=lnbg, density=cat["density"])
+        g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model, centre=(CENTRE_RA, CENTRE_DEC),
+                           precision=precision, **kw)
+        g.set_option("prefetch", 0)
+        off = g.loglike(params)
+        g.set_option("prefetch", 1)
+        on = g.loglike(params)
+        g.set_option("prefetch", -1)
+        auto = g.loglike(params)
+        g.close()
+        assert np.array_equal(off, on, equal_nan=True) and np.array_equal(off, auto, equal_nan=True), (n, off, on)
+    g2 = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=0, centre=(CENTRE_RA, CENTRE_DEC))
+    with pytest.raises(native.NativeError, match="prefetch"):
+        g2.set_option("prefetch", 2)
+    g2.close()
