@@ -567,15 +567,29 @@ def main():
         fit.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)     # pattern of bin/run_tests.py:92-93
         fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
         sampler = fit._make_sampler(n_walkers)             # emcee if importable, built-in stretch move otherwise
-        state = sampler.run_mcmc(pos, 3)
-        t2 = time.perf_counter()
-        n_mcmc = 30
-        sampler.run_mcmc(tuple(state)[0], n_mcmc)
-        dt = time.perf_counter() - t2
+        state = sampler.run_mcmc(pos, 80)                  # warm: a 64- and a 16-step block (work buffers, chain storage)
+        n_mcmc = 256                                       # four blocks of the built-in sampler (64 steps each)
+        start = tuple(state)[0]
+
+        def timed_chain():
+            t2 = time.perf_counter()
+            sampler.run_mcmc(start, n_mcmc)
+            return time.perf_counter() - t2
+
+        dt = timed_chain()
         mcmc = {"steps_per_s": n_mcmc / dt, "terms_per_s": float(len(cat["v"])) * n_walkers * n_mcmc / dt,
                 "driver": type(sampler).__module__ + "." + type(sampler).__name__,
                 "posterior": type(fit).__name__ + ".lnprob_batch", "calls_per_step": 2, "walkers_per_call": n_walkers // 2,
-                "acceptance_fraction": float(np.mean(sampler.acceptance_fraction))}
+                "steps": n_mcmc, "acceptance_fraction": float(np.mean(sampler.acceptance_fraction))}
+        fit_cat = getattr(fit, "_catalog", None)
+        if getattr(sampler, "block_fn", None) is not None and fit_cat is not None:
+            # where mcd_stretch_move ran its blocks (resident on the device / host-driven), and the host-driven rate of the
+            # same chain beside it (option "device_chain" = 0: one blocking evaluation per half step)
+            mcmc["stretch_blocks"] = fit_cat.stretch_info()
+            fit_cat.set_option("device_chain", 0)
+            dt_host = timed_chain()
+            fit_cat.set_option("device_chain", 1)
+            mcmc["host_driven_steps_per_s"] = n_mcmc / dt_host
         fit.close()
 
     # per-rank figures of the headline workload, gathered before the catalogue goes away

@@ -184,7 +184,17 @@ int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t
  * pos [W][n_dim] and lnp [W] are updated in place; chain [n_steps][W][n_dim], lnprob_chain [n_steps][W] (either may be
  * NULL) receive the state after every step; accepted [W] (may be NULL) is incremented.  The chain is bit-identical to the
  * one the Python loop produces from the same numbers.  Un-binned catalogues only.  Returns MCD_ERR_NONFINITE when the
- * likelihood produced a NaN (emcee raises "Probability function returned NaN"). */
+ * likelihood produced a NaN (emcee raises "Probability function returned NaN").
+ *
+ * Where it runs.  A float64 catalogue on one device per process (single GPU, or one rank of a multi-process job) keeps
+ * the ensemble RESIDENT on the device for the block: positions, log-probabilities and the block's random numbers are
+ * uploaded once, one small kernel per half step accepts / rejects the previous half step and proposes the next one
+ * (prior, resolved parameter rows, walker constants, range guard), and the whole block is a chain of launches the host
+ * waits for once -- no host round trip between two evaluations (option "device_chain", default 1; csrc/mcd_stretch.hip).
+ * The numbers are the host-driven loop's, bit for bit.  What only the host loop can handle -- a NaN, a re-run request of
+ * the fast mixture kernels, a proposal table for which the range guard picks another kernel family than was enqueued, a
+ * half step with every proposal outside the prior -- makes the library discard the block and run it host-driven from
+ * the same inputs; mcd_stretch_info counts both kinds. */
 typedef struct {
     int64_t n_walkers;          /* W, even */
     int32_t n_dim;              /* free parameters (columns of pos) */
@@ -201,6 +211,11 @@ typedef struct {
 int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* desc, int64_t n_steps, double* pos, double* lnp,
                      const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
                      double* lnprob_chain, int64_t* accepted);
+/* Blocks of mcd_stretch_move that ran resident on the device / host-driven, blocks the device discarded (they were then
+ * run host-driven and count there too) and the status bits of the last discarded one (1 NaN, 2 re-run request, 4 kernel
+ * family changed, 8 no proposal inside the prior).  Any pointer may be NULL. */
+int mcd_stretch_info(const mcd_catalog* cat, int64_t* device_blocks, int64_t* host_blocks, int64_t* discarded_blocks,
+                     int32_t* last_discard_status);
 
 /* ---- introspection for the measurement harness ------------------------------------------- */
 
@@ -228,11 +243,13 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *   "spin_us"       microseconds mcd_sync / fetch / batch poll the stream (hipStreamQuery) before they fall back to the
  *                      blocking hipStreamSynchronize, whose interrupt wake-up adds 50 - 500 us of jitter to waits longer
  *                      than a fraction of a millisecond (default 20000; 0: always block)
+ *   "device_chain"  1 (default): mcd_stretch_move keeps the ensemble resident on the device where it can (see there);
+ *                      0: host-driven blocks only
  *   "prefetch"      software prefetch of the star records of the next loop iteration: -1 (default) on for devices whose
  *                      share of the catalogue is at least 8 MiB of records (it hides the memory latency there, +1 % at
  *                      256 walkers to +45 % at 64 on 1e6 stars) and off below (the records stay in the caches; the
  *                      prefetch costs ~5 % there); 0 off, 1 on.  Results do not depend on it.
- *   "target_waves"  number of waves the chunking aims for per device (default 12288)
+ *   "target_waves"  number of waves the chunking aims for per device (default 10240)
  *   "chunk_len"     explicit nominal chunk length in stars (rounded up to a multiple of 32; 0, the default: derived from
  *                      "target_waves"); tuning aid
  *   "tail_split"    chunk schedule: 0 equal-length chunks; 1 (default): the last ~15 % of a large parameter set is

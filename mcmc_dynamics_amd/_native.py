@@ -51,6 +51,7 @@ SYMBOLS = {
     "mcd_stretch_move": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p,
                                         ctypes.POINTER(ctypes.c_int32), _c_double_p, _c_double_p,
                                         ctypes.POINTER(ctypes.c_int32), _c_double_p, _c_double_p, _c_int64_p]),
+    "mcd_stretch_info": (ctypes.c_int, [ctypes.c_void_p, _c_int64_p, _c_int64_p, _c_int64_p, ctypes.POINTER(ctypes.c_int32)]),
     "mcd_last_error": (ctypes.c_char_p, []),
     "mcd_abi_version": (ctypes.c_int, []),
     "mcd_last_kernel_ms": (ctypes.c_double, [ctypes.c_void_p]),
@@ -369,6 +370,14 @@ class Catalog(object):
                                        accepted.ctypes.data_as(_c_int64_p) if accepted is not None else None)
         _check(self.lib, rc, "mcd_stretch_move")
         self._walkers = w // 2
+
+    def stretch_info(self):
+        """Where the blocks of ``stretch_move`` ran: {'device_blocks', 'host_blocks', 'discarded_blocks', 'last_discard_status'}
+        (``mcd_stretch_info``: resident on the device / host-driven / discarded by the device and re-run host-driven)."""
+        a, b, c, st = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        _check(self.lib, self.lib.mcd_stretch_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(st)),
+               "mcd_stretch_info")
+        return {"device_blocks": a.value, "host_blocks": b.value, "discarded_blocks": c.value, "last_discard_status": st.value}
 
     def set_option(self, key, value):
         _check(self.lib, self.lib.mcd_set_option(self.handle, key.encode(), int(value)), "mcd_set_option")

@@ -138,6 +138,13 @@ struct WorkSet {
     bool staged = false;
 };
 
+// device arena of the resident stretch-move chain and its pinned host mirror (same layout, see stretch_block_device)
+struct ChainArena {
+    char* d = nullptr;
+    char* h = nullptr;
+    size_t bytes = 0;
+};
+
 struct Shard {
     int slot = 0;                      // index into ctx->slots
     int64_t star_begin = 0;            // global index of the first star held here
@@ -181,7 +188,7 @@ struct mcd_catalog {
     int64_t timing_launches = 0;
     int64_t spin_us = 20000;           // option "spin_us": poll a stream this long before blocking in hipStreamSynchronize
     int tail_split = 1;                // guided chunk schedule (shorter chunks at the end of a launch)
-    int64_t target_waves = 12288;
+    int64_t target_waves = 10240;      // see mcd_chunks.h: plan_chunks
     int64_t chunk_len = 0;             // option "chunk_len": explicit nominal chunk length (0: from target_waves)
     int prefetch = -1;                 // option "prefetch": -1 by record volume (>= 8 MiB per device), 0 off, 1 on
     // state of the last evaluation
@@ -191,6 +198,14 @@ struct mcd_catalog {
     int64_t last_grid = 0, last_chunks = 0;
     uint64_t launch_seq = 0;           // source of launch tags
     int64_t n_reruns = 0;              // batches re-evaluated with the plain kernels (denormal regime of the reference)
+    // resident stretch-move chain (mcd_stretch.hip)
+    int device_chain = 1;              // option "device_chain": 0 host-driven blocks only
+    ChainArena chain;
+    int chain_hint = -1;               // kernel family the device's guard asked for when it last disagreed (-1: none)
+    int64_t chain_backoff = 0;         // blocks left to run host-driven after a discarded block
+    int chain_consecutive = 0;         // discarded blocks in a row (the back-off doubles with each)
+    int64_t chain_device_blocks = 0, chain_host_blocks = 0, chain_discarded = 0;
+    int chain_last_status = 0;         // status word of the last discarded block (mcd::ChainStatus bits)
 };
 
 namespace {
@@ -569,6 +584,206 @@ int fetch(mcd_catalog* cat, double* out) {
     return MCD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// mcd_stretch_move with the ensemble resident on the device (mcd_stretch.hip).  Runs the whole block as one chain of
+// launches and waits once.  *done = false (and nothing of the caller's touched) when the block has to be run host-driven:
+// the configuration is not covered, or the device met something only the host loop handles (mcd::ChainStatus).
+int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
+                         const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
+                         double* lnprob_chain, int64_t* accepted, bool* done) {
+    *done = false;
+    mcd_ctx* ctx = cat->ctx;
+    if (!cat->device_chain || cat->shards.size() != 1 || cat->precision != MCD_F64 || cat->n_psets != 1 || n_steps < 1 ||
+        cat->timing || !d->fixed_ok)
+        return MCD_OK;
+    if (cat->chain_backoff > 0) { --cat->chain_backoff; return MCD_OK; }
+    const int64_t W = d->n_walkers, half = W / 2;
+    const int P = d->n_dim, K = d->k;
+    Shard& sh = cat->shards[0];
+    const DeviceSlot& slot = ctx->slots[sh.slot];
+    MCD_HIP(hipSetDevice(slot.device));
+    WorkSet* wp = nullptr;
+    int rc = build_workset(cat, sh, half, &wp);
+    if (rc != MCD_OK) return rc;
+    WorkSet& w = *wp;
+    // nothing of an earlier call may still use the work buffers, the arena or the communicator
+    MCD_HIP(wait_stream(slot.stream, cat->spin_us));
+    MCD_HIP(wait_stream(slot.comm_stream, cat->spin_us));
+    w.comm_pending[0] = w.comm_pending[1] = false;
+    w.staged = false;                     // the walker constants are about to be overwritten on the device
+
+    // ---- arena layout: [state, copied both ways | inputs, copied in | scratch | chain rows, copied out] ----
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 63) / 64 * 64; return at; };
+    const size_t o_pos = take((size_t)W * P * 8), o_lnp = take((size_t)W * 8), o_acc = take((size_t)W * 8);
+    const size_t o_meta = take(mcd::META_WORDS * 4), o_status = take(8);
+    const size_t state_end = off;
+    const size_t o_src = take((size_t)K * 4), o_const = take((size_t)K * 8), o_fac = take((size_t)K * 8);
+    const size_t o_lo = take((size_t)P * 8), o_hi = take((size_t)P * 8);
+    const size_t o_order = take((size_t)n_steps * W * 4), o_zz = take((size_t)n_steps * W * 8);
+    const size_t o_thr = take((size_t)n_steps * W * 8), o_pick = take((size_t)n_steps * W * 4);
+    const size_t input_end = off;
+    const size_t o_prop = take((size_t)half * P * 8), o_ok = take((size_t)half);
+    const size_t o_chain = take(chain ? (size_t)n_steps * W * P * 8 : 0);
+    const size_t o_lnpc = take(lnprob_chain ? (size_t)n_steps * W * 8 : 0);
+    const size_t total = off;
+    ChainArena& a = cat->chain;
+    if (a.bytes < total) {
+        if (a.d) (void)hipFree(a.d);
+        if (a.h) (void)hipHostFree(a.h);
+        a = ChainArena();
+        const size_t want = total + total / 2;
+        if (hipMalloc((void**)&a.d, want) != hipSuccess) { a = ChainArena(); return fail(MCD_ERR_HIP, "mcd_stretch_move: device arena"); }
+        if (hipHostMalloc((void**)&a.h, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipFree(a.d);
+            a = ChainArena();
+            return fail(MCD_ERR_HIP, "mcd_stretch_move: pinned arena");
+        }
+        a.bytes = want;
+    }
+    std::memcpy(a.h + o_pos, pos, (size_t)W * P * 8);
+    std::memcpy(a.h + o_lnp, lnp, (size_t)W * 8);
+    if (accepted) std::memcpy(a.h + o_acc, accepted, (size_t)W * 8);
+    else std::memset(a.h + o_acc, 0, (size_t)W * 8);
+    std::memset(a.h + o_meta, 0, mcd::META_WORDS * 4);
+    std::memset(a.h + o_status, 0, 8);
+    std::memcpy(a.h + o_src, d->col_source, (size_t)K * 4);
+    std::memcpy(a.h + o_const, d->col_const, (size_t)K * 8);
+    std::memcpy(a.h + o_fac, d->col_factor, (size_t)K * 8);
+    std::memcpy(a.h + o_lo, d->lo, (size_t)P * 8);
+    std::memcpy(a.h + o_hi, d->hi, (size_t)P * 8);
+    std::memcpy(a.h + o_order, order, (size_t)n_steps * W * 4);
+    std::memcpy(a.h + o_zz, zz, (size_t)n_steps * W * 8);
+    std::memcpy(a.h + o_thr, thr, (size_t)n_steps * W * 8);
+    std::memcpy(a.h + o_pick, pick, (size_t)n_steps * W * 4);
+
+    // kernel family of this block: what the device's guard last asked for, else the verdict on the current positions
+    int level = cat->chain_hint;
+    if (level < 0) {
+        std::vector<double> table((size_t)W * K);
+        for (int64_t j = 0; j < W; ++j)
+            for (int c = 0; c < K; ++c) {
+                const int src = d->col_source[c];
+                table[j * K + c] = src < 0 ? d->col_const[c]
+                                           : (d->col_factor[c] == 1.0 ? pos[j * P + src] : pos[j * P + src] * d->col_factor[c]);
+            }
+        level = fast_level(cat, table.data(), W);
+    }
+
+    mcd::StretchDevice sd;
+    sd.n_walkers = W; sd.n_dim = P; sd.k = K; sd.fixed_ok = d->fixed_ok;
+    sd.model = cat->model; sd.free_centre = cat->free_centre ? 1 : 0; sd.allow_fast = cat->allow_fast;
+    sd.expected_level = level;
+    sd.force_general = cat->device_chain == 2;
+    sd.stats = cat->stats;                                              // (slices to the scalar part)
+    sd.col_source = (const int32_t*)(a.d + o_src); sd.col_const = (const double*)(a.d + o_const);
+    sd.col_factor = (const double*)(a.d + o_fac); sd.lo = (const double*)(a.d + o_lo); sd.hi = (const double*)(a.d + o_hi);
+    sd.pos = (double*)(a.d + o_pos); sd.lnp = (double*)(a.d + o_lnp); sd.accepted = (long long*)(a.d + o_acc);
+    sd.order = (const int32_t*)(a.d + o_order); sd.zz = (const double*)(a.d + o_zz); sd.thr = (const double*)(a.d + o_thr);
+    sd.pick = (const int32_t*)(a.d + o_pick);
+    sd.chain = chain ? (double*)(a.d + o_chain) : nullptr;
+    sd.lnprob_chain = lnprob_chain ? (double*)(a.d + o_lnpc) : nullptr;
+    sd.proposal = (double*)(a.d + o_prop); sd.ok = (uint8_t*)(a.d + o_ok); sd.meta = (int32_t*)(a.d + o_meta);
+    sd.table = w.d_params; sd.wpar = (double*)w.d_wpar;
+
+    MCD_HIP(hipMemcpyAsync(a.d, a.h, input_end, hipMemcpyHostToDevice, slot.stream));
+    const bool coll = ctx->n_ranks > 1 || ctx->force_collective;
+    mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, level, w.uniform_len, sh.n};
+    shape.chunk_general = w.d_chunk_general;
+    shape.prefetch = cat->prefetch >= 0 ? cat->prefetch != 0
+                                        : (size_t)sh.n * (size_t)mcd::record_bytes(cat->model, cat->free_centre, cat->precision) >= ((size_t)8 << 20);
+    double* const out_buf = w.d_out;
+    shape.rerun_flag = coll ? nullptr : out_buf + half;
+    const int bgk = mcd::bg_kind(cat->model);
+    const double* pset_const = (level && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
+    double prev_tag = 0.0;
+    int64_t acc_step = -1;
+    int acc_h = 0;
+#ifdef MCD_CHAIN_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) MCD_HIP(hipMalloc((void**)&d_stamps, 8 * 8 * 4096));
+    MCD_HIP(hipMemsetAsync(d_stamps, 0, 8 * 8 * 4096, slot.stream));
+    sd.stamps = d_stamps;
+#endif
+    for (int64_t i = 0; i < n_steps; ++i)
+        for (int h = 0; h < 2; ++h) {
+#ifdef MCD_CHAIN_STAMPS
+            sd.launch_index = i * 2 + h;
+#endif
+            MCD_HIP(mcd::launch_stretch_step(slot.stream, sd, acc_step, acc_h, i, h, out_buf, prev_tag));
+            prev_tag = coll ? 0.0 : (double)(++cat->launch_seq);
+            shape.launch_tag = prev_tag;
+            MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, half));
+            MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, 1, w.n_chunks, w.max_chunks_per_pset, half,
+                                       pset_const, out_buf));
+            if (coll) {
+                if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
+                MCD_NCCL(g_rccl.AllReduce(out_buf, out_buf, (size_t)half, ncclDouble, ncclSum, slot.comm, slot.stream));
+                if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
+            }
+            acc_step = i;
+            acc_h = h;
+        }
+    MCD_HIP(mcd::launch_stretch_step(slot.stream, sd, acc_step, acc_h, -1, 0, out_buf, prev_tag));
+    if (coll) {
+        // ranks hold different shares of the catalogue, so their guard verdicts may differ: all discard the block if one does
+        double* status = (double*)(a.d + o_status);
+        MCD_HIP(mcd::launch_stretch_status(slot.stream, sd.meta, status));
+        if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
+        MCD_NCCL(g_rccl.AllReduce(status, status, 1, ncclDouble, ncclSum, slot.comm, slot.stream));
+        if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
+    }
+    MCD_HIP(hipMemcpyAsync(a.h, a.d, state_end, hipMemcpyDeviceToHost, slot.stream));
+    if (total > o_chain)
+        MCD_HIP(hipMemcpyAsync(a.h + o_chain, a.d + o_chain, total - o_chain, hipMemcpyDeviceToHost, slot.stream));
+    MCD_HIP(wait_stream(slot.stream, cat->spin_us));
+#ifdef MCD_CHAIN_STAMPS
+    {
+        const int64_t n = std::min<int64_t>(n_steps * 2, 4096);
+        std::vector<unsigned long long> st((size_t)n * 8);
+        MCD_HIP(hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        double sum[8] = {0}, period = 0;
+        int64_t cnt = 0;
+        for (int64_t i = 2; i + 1 < n; ++i) {
+            for (int k = 1; k < 8; ++k) sum[k] += (double)(st[i * 8 + k] - st[i * 8 + k - 1]);
+            period += (double)(st[(i + 1) * 8] - st[i * 8]);
+            ++cnt;
+        }
+        if (cnt > 0) {
+            fprintf(stderr, "[chain stamps] period %.2f us; phases (us):", period / cnt / 100.0);
+            for (int k = 1; k < 8; ++k) fprintf(stderr, " %d:%.2f", k, sum[k] / cnt / 100.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+
+    w.fast = level;
+    cat->cur_walkers = half;
+    cat->last_chunks = w.n_chunks;
+    cat->last_grid = mcd::main_grid(w.n_chunks, half);
+    const int32_t* meta = (const int32_t*)(a.h + o_meta);
+    const bool discard = meta[mcd::META_STATUS] != 0 || (coll && *(const double*)(a.h + o_status) != 0.0);
+    if (discard) {
+        ++cat->chain_discarded;
+        cat->chain_last_status = meta[mcd::META_STATUS];
+        cat->chain_hint = (meta[mcd::META_STATUS] & mcd::CHAIN_LEVEL) ? meta[mcd::META_LEVEL] : -1;
+        // every rank of a job counts the same discards (the verdict above is collective), so the back-off stays in step
+        cat->chain_consecutive = std::min(cat->chain_consecutive + 1, 7);
+        cat->chain_backoff = cat->chain_consecutive > 1 ? ((int64_t)1 << (cat->chain_consecutive - 1)) : 0;
+        return MCD_OK;
+    }
+    cat->chain_consecutive = 0;
+    cat->chain_hint = level;
+    ++cat->chain_device_blocks;
+    std::memcpy(pos, a.h + o_pos, (size_t)W * P * 8);
+    std::memcpy(lnp, a.h + o_lnp, (size_t)W * 8);
+    if (accepted) std::memcpy(accepted, a.h + o_acc, (size_t)W * 8);
+    if (chain) std::memcpy(chain, a.h + o_chain, (size_t)n_steps * W * P * 8);
+    if (lnprob_chain) std::memcpy(lnprob_chain, a.h + o_lnpc, (size_t)n_steps * W * 8);
+    *done = true;
+    return MCD_OK;
+}
+
 int make_slot(int device, DeviceSlot* slot) {
     MCD_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -823,6 +1038,8 @@ int mcd_catalog_destroy(mcd_catalog* cat) {
         if (sh.ev_end) (void)hipEventDestroy(sh.ev_end);
         for (auto& pr : sh.ring) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     }
+    if (cat->chain.d) (void)hipFree(cat->chain.d);
+    if (cat->chain.h) (void)hipHostFree(cat->chain.h);
     delete cat;
     return MCD_OK;
 }
@@ -958,6 +1175,11 @@ int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_step
     mcd::StretchDesc sd;
     sd.n_walkers = W; sd.n_dim = d->n_dim; sd.k = d->k; sd.col_source = d->col_source; sd.col_const = d->col_const;
     sd.col_factor = d->col_factor; sd.lo = d->lo; sd.hi = d->hi; sd.fixed_ok = d->fixed_ok;
+    bool done = false;
+    const int dev_rc = stretch_block_device(cat, d, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted, &done);
+    if (dev_rc != MCD_OK) return dev_rc;
+    if (done) return MCD_OK;
+    ++cat->chain_host_blocks;
     int eval_rc = MCD_OK;
     const int rc = mcd::stretch_block(sd, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted,
                                       [&](const double* table, int64_t n, double* out) {
@@ -1017,6 +1239,15 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     if (!std::strcmp(key, "zero_copy")) { cat->zero_copy = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "device_chain")) {
+        if (value < 0 || value > 2)
+            return fail(MCD_ERR_INVALID, "device_chain: 0 (host-driven blocks), 1 (default) or 2 (as 1 with the general step kernel, testing aid)");
+        cat->device_chain = (int)value;
+        cat->chain_backoff = 0;
+        cat->chain_consecutive = 0;
+        cat->chain_hint = -1;
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "prefetch")) {
         if (value < -1 || value > 1) return fail(MCD_ERR_INVALID, "prefetch: -1 (by record volume, default), 0 (off) or 1 (on)");
         cat->prefetch = (int)value;
@@ -1066,6 +1297,16 @@ int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_lau
 }
 
 int64_t mcd_rerun_count(const mcd_catalog* cat) { return cat ? cat->n_reruns : MCD_ERR_INVALID; }
+
+int mcd_stretch_info(const mcd_catalog* cat, int64_t* device_blocks, int64_t* host_blocks, int64_t* discarded_blocks,
+                     int32_t* last_discard_status) {
+    if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
+    if (device_blocks) *device_blocks = cat->chain_device_blocks;
+    if (host_blocks) *host_blocks = cat->chain_host_blocks;
+    if (discarded_blocks) *discarded_blocks = cat->chain_discarded;
+    if (last_discard_status) *last_discard_status = cat->chain_last_status;
+    return MCD_OK;
+}
 
 int mcd_last_fast_level(const mcd_catalog* cat) {
     if (!cat || cat->cur_walkers <= 0 || cat->shards.empty()) return -1;

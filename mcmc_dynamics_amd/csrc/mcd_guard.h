@@ -1,5 +1,6 @@
-// mcd_guard.h -- host-side range guard that decides, per call, whether the fast kernel formulations may be used.
-// Shared by the C-ABI (mcd_api.hip) and by the CPU test harness (tests/emul), so that the randomized tests exercise
+// mcd_guard.h -- range guard that decides, per call, whether the fast kernel formulations may be used.
+// Shared by the C-ABI (mcd_api.hip), by the resident stretch-move chain (mcd_stretch.hip evaluates the same verdict on the
+// device for the tables it builds there) and by the CPU test harness (tests/emul), so that the randomized tests exercise
 // exactly the condition the library applies.
 #pragma once
 
@@ -13,17 +14,23 @@
 
 namespace mcd {
 
-// Range statistics of one catalogue, gathered at upload.
-struct CatalogStats {
+constexpr double kInfinity = std::numeric_limits<double>::infinity();
+
+// Range statistics of one catalogue, gathered at upload.  The scalar part travels to the device by value (the resident
+// stretch-move chain re-evaluates the guard there, mcd_stretch.hip).
+struct StatsScalars {
     double e2_min = 0, e2_max = 0, v_abs_max = 0;   // verr^2 range, max |v|
     double rho_min = 0, rho_max = 0;                // density range (BG_GAUSS / BG_FIXED_DENSITY)
+    double lnbg_min = 0, lnbg_max = 0, pm_max = 0;  // ranges of the fixed background columns (float32 fast mixtures)
     bool stats_finite = true;                       // v, verr all finite
     bool extras_ok = true;                          // background columns inside the fast-path ranges
+    bool narrow_possible = false;                   // at most 1/8 of the stars are exceptions (else: general form throughout)
+};
+
+struct CatalogStats : StatsScalars {
     // Stars that rule out the narrow-range variants for the CHUNK that holds them (narrow_exception below), ascending
     // indices; the kernel then takes the general fast form for those chunks only (LaunchShape::chunk_general).
     std::vector<int64_t> narrow_exceptions;
-    bool narrow_possible = false;                   // at most 1/8 of the stars are exceptions (else: general form throughout)
-    double lnbg_min = 0, lnbg_max = 0, pm_max = 0;  // ranges of the fixed background columns (float32 fast mixtures)
 };
 
 // BGFIXED: a certain member (pmember == 1: the mixture value y = (1 - p) + ... has no floor) or lnL_bg < -60 (y can
@@ -106,48 +113,74 @@ struct GuardRanges {
     double f_min = 0, f_max = 0;        // f_back (BG_GAUSS, BG_FIXED_DENSITY)
 };
 
-inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
-                       int64_t n_rows, GuardRanges* ranges = nullptr) {
-    if (!st.stats_finite || n_rows == 0) return false;
+// Ranges of one parameter table, gathered row by row.  Only min / max of per-row quantities: the result does not depend
+// on the order in which rows (or partial results, merge()) are visited, so a parallel reduction on the device and the
+// serial loop on the host give the same bits.
+struct ParamRanges {
+    double s2_min = kInfinity, s2_max = 0.0, amp = 0.0, sb2_min = kInfinity, sb2_max = 0.0, f_min = kInfinity, f_max = 0.0;
+    double len_min = kInfinity, len_max = 0.0;                 // a and r_peak of the profile models
+    bool finite = true;                                        // every row finite where the guard needs it
 
-    const bool prof = is_profile(model);
-    const int bg = bg_kind(model);
-    const int ix = prof ? 3 : 2, iy = prof ? 4 : 3;
-    const double inf = std::numeric_limits<double>::infinity();
-    double s2_min = inf, s2_max = 0.0, amp = 0.0, sb2_min = inf, sb2_max = 0.0, f_min = inf, f_max = 0.0;
-    double len_min = inf, len_max = 0.0;                       // a and r_peak of the profile models
-    for (int64_t i = 0; i < n_rows; ++i) {
-        const double* p = params + i * k;
+    MCD_HD static double lesser(double a, double b) { return b < a ? b : a; }
+    MCD_HD static double greater(double a, double b) { return a < b ? b : a; }
+
+    MCD_HD void add_row(const double* p, int k, int model, bool free_centre) {
+        const bool prof = is_profile(model);
+        const int bg = bg_kind(model);
+        const int ix = prof ? 3 : 2, iy = prof ? 4 : 3;
         const double s2 = p[1] * p[1];
-        double a = std::fabs(p[0]) + std::fabs(p[ix]) + std::fabs(p[iy]);
-        if (prof) {
-            if (!(std::isfinite(p[2]) && std::isfinite(p[5]))) return false;
-            len_min = std::min(len_min, std::min(p[2], p[5]));
-            len_max = std::max(len_max, std::max(p[2], p[5]));
-        }
+        double a = fabs(p[0]) + fabs(p[ix]) + fabs(p[iy]);
+        bool ok = true;
+        if (prof) ok = ok && finite_value(p[2]) && finite_value(p[5]);
+        double sb2 = 0.0, f = 0.0;
         if (bg == BG_GAUSS) {
-            const double sb2 = p[k - 2] * p[k - 2];
-            a = std::max(a, std::fabs(p[k - 3]));
-            if (!std::isfinite(sb2)) return false;
-            sb2_min = std::min(sb2_min, sb2); sb2_max = std::max(sb2_max, sb2);
+            sb2 = p[k - 2] * p[k - 2];
+            a = greater(a, fabs(p[k - 3]));
+            ok = ok && finite_value(sb2);
         }
         if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) {
-            const double f = p[k - 1];
-            if (!std::isfinite(f)) return false;
-            f_min = std::min(f_min, f); f_max = std::max(f_max, f);
+            f = p[k - 1];
+            ok = ok && finite_value(f);
         }
         if (free_centre) {
             const int ic = prof ? 6 : 4;
-            if (!(std::isfinite(p[ic]) && std::isfinite(p[ic + 1]))) return false;
+            ok = ok && finite_value(p[ic]) && finite_value(p[ic + 1]);
         }
-        if (!(std::isfinite(s2) && std::isfinite(a))) return false;
-        s2_min = std::min(s2_min, s2);
-        s2_max = std::max(s2_max, s2);
-        amp = std::max(amp, a);
+        ok = ok && finite_value(s2) && finite_value(a);
+        if (!ok) { finite = false; return; }                   // the verdict is "plain kernels" whatever the other rows hold
+        if (prof) {
+            len_min = lesser(len_min, lesser(p[2], p[5]));
+            len_max = greater(len_max, greater(p[2], p[5]));
+        }
+        if (bg == BG_GAUSS) { sb2_min = lesser(sb2_min, sb2); sb2_max = greater(sb2_max, sb2); }
+        if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) { f_min = lesser(f_min, f); f_max = greater(f_max, f); }
+        s2_min = lesser(s2_min, s2);
+        s2_max = greater(s2_max, s2);
+        amp = greater(amp, a);
     }
+
+    MCD_HD void merge(const ParamRanges& o) {
+        s2_min = lesser(s2_min, o.s2_min); s2_max = greater(s2_max, o.s2_max); amp = greater(amp, o.amp);
+        sb2_min = lesser(sb2_min, o.sb2_min); sb2_max = greater(sb2_max, o.sb2_max);
+        f_min = lesser(f_min, o.f_min); f_max = greater(f_max, o.f_max);
+        len_min = lesser(len_min, o.len_min); len_max = greater(len_max, o.len_max);
+        finite = finite && o.finite;
+    }
+
+    MCD_HD static bool finite_value(double x) { return fabs(x) <= 1.7976931348623157e308; }   // false for NaN and +-inf
+};
+
+// The verdict from the catalogue's statistics and a table's ranges.
+MCD_HD bool guard_verdict(const StatsScalars& st, int model, bool f32, int64_t n_rows, const ParamRanges& pr,
+                          GuardRanges* ranges) {
+    if (!st.stats_finite || n_rows == 0 || !pr.finite) return false;
+    const bool prof = is_profile(model);
+    const int bg = bg_kind(model);
+    const double s2_min = pr.s2_min, s2_max = pr.s2_max, amp = pr.amp, sb2_min = pr.sb2_min, sb2_max = pr.sb2_max;
+    const double f_min = pr.f_min, f_max = pr.f_max, len_min = pr.len_min, len_max = pr.len_max;
     // |v - v_los| <= |v| + |v_sys| + |v_max| (the Lynden-Bell factor 2 r r_peak / (r^2 + r_peak^2) is <= 1)
     const double d_max = st.v_abs_max + amp;
-    if (!(d_max <= std::ldexp(1.0, 58))) return false;
+    if (!(d_max <= 0x1p58)) return false;
     // sigma_los of the profile models decays to 0 at large r: only verr^2 bounds the variance from below
     const double n_min = st.e2_min + (prof ? 0.0 : s2_min), n_max = st.e2_max + s2_max;
     if (ranges) {
@@ -155,42 +188,42 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
         ranges->nb_min = st.e2_min + sb2_min; ranges->nb_max = st.e2_max + sb2_max;
         ranges->f_min = f_min; ranges->f_max = f_max;
     }
-    if (prof && !(len_min >= std::ldexp(1.0, -100) && len_max <= std::ldexp(1.0, 100))) return false;   // a, r_peak > 0
+    if (prof && !(len_min >= 0x1p-100 && len_max <= 0x1p100)) return false;   // a, r_peak > 0
     if (bg == BG_NONE) {
         if (f32)      // 4-star tree in f32: DEN <= 2^60, NUM <= 2^77
-            return (n_min >= std::ldexp(1.0, -15)) && (n_max <= std::ldexp(1.0, 15)) && (d_max <= std::ldexp(1.0, 15)) &&
-                   (!prof || (len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20)));
+            return (n_min >= 0x1p-15) && (n_max <= 0x1p15) && (d_max <= 0x1p15) &&
+                   (!prof || (len_min >= 0x1p-20 && len_max <= 0x1p20));
         // 16-star tree of MODEL_CONST: DEN = prod of 16 norms within 2^+-880, NUM <= q norm^15 <= 2^100 2^825
-        return (n_min >= std::ldexp(1.0, -55)) && (n_max <= std::ldexp(1.0, 55)) && (d_max <= std::ldexp(1.0, 50));
+        return (n_min >= 0x1p-55) && (n_max <= 0x1p55) && (d_max <= 0x1p50);
     }
     if (f32) {
         // float32 fast mixtures (BgFixedAccF / BgGaussAccF): four mixture values y are multiplied in float between two
         // rescales, so every y must stay within [2^-30, 2^30]; variances and residuals inside the float range of (d g)^2.
-        const double flo = std::ldexp(1.0, -15), fhi = std::ldexp(1.0, 15);
+        const double flo = 0x1p-15, fhi = 0x1p15;
         if (!(n_min >= flo && n_max <= fhi && d_max <= fhi && st.extras_ok)) return false;
-        if (prof && !(len_min >= std::ldexp(1.0, -20) && len_max <= std::ldexp(1.0, 20))) return false;
-        const double g_max_log2 = -0.5 * std::log2(n_min), kLog2e = 1.4426950408889634;
+        if (prof && !(len_min >= 0x1p-20 && len_max <= 0x1p20)) return false;
+        const double g_max_log2 = -0.5 * log2(n_min), kLog2e = 1.4426950408889634;
         if (bg == BG_FIXED) {
             // y = (1 - p) + g e^{u},  u <= log p - lnL_bg - 1/2 log 2pi:  lower bound 1 - p, upper 1 + g_max e^{-lnL_bg,min}
             if (!(st.pm_max <= 1.0 - 0x1p-20 && st.lnbg_max <= 60.0 && st.lnbg_min >= -80.0)) return false;
-            return std::max(0.0, -(st.lnbg_min + kHalfLn2Pi) * kLog2e + g_max_log2) + 1.0 <= 30.0;
+            return ParamRanges::greater(0.0, -(st.lnbg_min + kHalfLn2Pi) * kLog2e + g_max_log2) + 1.0 <= 30.0;
         }
         if (bg == BG_FIXED_DENSITY) {
             // y = f + g e^{u},  u <= log rho - lnL_bg - 1/2 log 2pi
             if (!(f_min >= 0x1p-20 && f_max <= 0x1p20 && st.rho_min >= 0.0 && st.lnbg_max <= 60.0 && st.lnbg_min >= -80.0)) return false;
-            const double up = std::log2(std::max(st.rho_max, 0x1p-60)) - (st.lnbg_min + kHalfLn2Pi) * kLog2e + g_max_log2;
-            return std::max(std::log2(f_max), up) + 1.0 <= 30.0 && st.rho_min + f_min >= 0x1p-30 && st.rho_max + f_max <= 0x1p30;
+            const double up = log2(ParamRanges::greater(st.rho_max, 0x1p-60)) - (st.lnbg_min + kHalfLn2Pi) * kLog2e + g_max_log2;
+            return ParamRanges::greater(log2(f_max), up) + 1.0 <= 30.0 && st.rho_min + f_min >= 0x1p-30 && st.rho_max + f_max <= 0x1p30;
         }
         // BG_GAUSS: y = rho g + f gb e^{-delta} (or mirrored): between min and sum of the two undamped terms
         if (!(st.e2_min + sb2_min >= flo && st.e2_max + sb2_max <= fhi)) return false;
         if (!(f_min >= 0x1p-20 && f_max <= 0x1p20 && st.rho_min >= 0x1p-20 && st.rho_max <= 0x1p20)) return false;
-        const double gb_max_log2 = -0.5 * std::log2(st.e2_min + sb2_min);
-        const double g_min_log2 = -0.5 * std::log2(n_max), gb_min_log2 = -0.5 * std::log2(st.e2_max + sb2_max);
-        const double hi2 = std::max(std::log2(st.rho_max) + g_max_log2, std::log2(f_max) + gb_max_log2) + 1.0;
-        const double lo2 = std::min(std::log2(st.rho_min) + g_min_log2, std::log2(f_min) + gb_min_log2);
+        const double gb_max_log2 = -0.5 * log2(st.e2_min + sb2_min);
+        const double g_min_log2 = -0.5 * log2(n_max), gb_min_log2 = -0.5 * log2(st.e2_max + sb2_max);
+        const double hi2 = ParamRanges::greater(log2(st.rho_max) + g_max_log2, log2(f_max) + gb_max_log2) + 1.0;
+        const double lo2 = ParamRanges::lesser(log2(st.rho_min) + g_min_log2, log2(f_min) + gb_min_log2);
         return hi2 <= 30.0 && lo2 >= -30.0;
     }
-    const double lo = std::ldexp(1.0, -200), hi = std::ldexp(1.0, 200);
+    const double lo = 0x1p-200, hi = 0x1p200;
     if (!((n_min >= lo) && (n_max <= hi))) return false;
     // exponent arguments stay below 1e9 in magnitude: (|v| + |v_los|)^2 / norm_min <= 1.6e9
     if (!(d_max * d_max <= 1.6e9 * n_min)) return false;
@@ -200,7 +233,7 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
         if (!(d_max * d_max <= 1.6e9 * (st.e2_min + sb2_min))) return false;
     }
     if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY)
-        return f_min >= 0.0 && (st.rho_min + f_min >= std::ldexp(1.0, -100)) && (st.rho_max + f_max <= std::ldexp(1.0, 100));
+        return f_min >= 0.0 && (st.rho_min + f_min >= 0x1p-100) && (st.rho_max + f_max <= 0x1p100);
     return true;
 }
 
@@ -208,10 +241,9 @@ inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool
 // a narrow_exception star still run the fast formulation of level 1).
 // BGFIXED (BgFixedAcc::add<.., NARROW>): pmember < 1 (so every mixture value y >= 1 - p >= 2^-53), lnlike_bg >= -60 and
 // norm >= 2^-60 (so y <= 1 + norm^-1/2 e^60 < 2^120): eight raw factors fit between rescales; |v - v_los|^2 <= 2e6 norm.
-inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
-                      int64_t n_rows) {
+MCD_HD int level_verdict(const StatsScalars& st, int model, bool f32, int64_t n_rows, const ParamRanges& pr) {
     GuardRanges g;
-    if (!fast_guard(st, model, free_centre, f32, k, params, n_rows, &g)) return 0;
+    if (!guard_verdict(st, model, f32, n_rows, pr, &g)) return 0;
     if (f32) return 1;
     const double lo = 0x1p-60, hi = 0x1p60;
     // Per-call conditions of the narrow-range variants (the per-star ones are CatalogStats::narrow_exceptions):
@@ -224,9 +256,25 @@ inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool 
         return 2;
     // BgGaussAcc::add<.., NARROW>: y >= the undamped term min(rho g, f g_b) >= 2^-20 2^-31 and y <= (rho + f) 2^31 <= 2^52
     if (bg_kind(model) == BG_GAUSS && g.f_min >= 0x1p-20 && g.f_max <= 0x1p20 && g.n_min >= lo && g.n_max <= hi &&
-        g.nb_min >= lo && g.nb_max <= hi && g.d_max * g.d_max <= 2.0e6 * std::min(g.n_min, g.nb_min))
+        g.nb_min >= lo && g.nb_max <= hi && g.d_max * g.d_max <= 2.0e6 * ParamRanges::lesser(g.n_min, g.nb_min))
         return 2;
     return 1;
+}
+
+inline ParamRanges table_ranges(int model, bool free_centre, int k, const double* params, int64_t n_rows) {
+    ParamRanges pr;
+    for (int64_t i = 0; i < n_rows; ++i) pr.add_row(params + i * k, k, model, free_centre);
+    return pr;
+}
+
+inline bool fast_guard(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
+                       int64_t n_rows, GuardRanges* ranges = nullptr) {
+    return guard_verdict(st, model, f32, n_rows, table_ranges(model, free_centre, k, params, n_rows), ranges);
+}
+
+inline int fast_level(const CatalogStats& st, int model, bool free_centre, bool f32, int k, const double* params,
+                      int64_t n_rows) {
+    return level_verdict(st, model, f32, n_rows, table_ranges(model, free_centre, k, params, n_rows));
 }
 
 }  // namespace mcd

@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "mcd_chunks.h"   // Chunk, chunk-table planning (host-only, shared with the CPU tests)
+#include "mcd_guard.h"    // StatsScalars: the range guard's catalogue statistics travel to the device by value
 
 namespace mcd {
 
@@ -54,6 +55,52 @@ hipError_t launch_per_star(hipStream_t s, const LaunchShape& shape, const void* 
                            const void* wpar_row, int mode, double* out);
 
 int record_bytes(int model, bool free_centre, int precision);
+
+// ---- resident stretch-move chain (mcd_stretch.hip): all pointers are device memory of ONE device ----
+enum ChainMeta : int { META_N_OK = 0, META_STATUS = 1, META_LEVEL = 2, META_WORDS = 4 };
+enum ChainStatus : int {
+    CHAIN_NAN = 1,           // a log-likelihood came back NaN (genuine, or the NaN-poisoned re-run signal of a multi-rank job)
+    CHAIN_RERUN = 2,         // a fast mixture kernel asked for the plain kernels (single device: tag behind the sums)
+    CHAIN_LEVEL = 4,         // the guard's verdict on a proposed table differs from the kernel family that was enqueued
+    CHAIN_NO_PROPOSAL = 8    // a half step without a single proposal inside the prior (the host loop skips the evaluation)
+};
+struct StretchDevice {
+    int64_t n_walkers = 0;                 // W (even)
+    int32_t n_dim = 0, k = 0;              // free parameters; columns of the kernel parameter table
+    int32_t fixed_ok = 1;
+    int32_t model = 0, free_centre = 0;
+    int32_t allow_fast = 1;                // option "fast_path"
+    int32_t expected_level = 0;            // LaunchShape::fast the main kernels of this block are enqueued with
+#ifdef MCD_CHAIN_STAMPS
+    unsigned long long* stamps = nullptr;  // development aid: 8 timestamps (100 MHz) per step-kernel launch
+    long long launch_index = 0;
+#endif
+    int32_t force_general = 0;             // testing aid (option "device_chain" = 2): the general step kernel for any size
+    StatsScalars stats;                    // this device's share of the catalogue
+    const int32_t* col_source = nullptr;   // [k]   as mcd::StretchDesc (mcd_stretch.h)
+    const double* col_const = nullptr;     // [k]
+    const double* col_factor = nullptr;    // [k]
+    const double* lo = nullptr;            // [P]
+    const double* hi = nullptr;            // [P]
+    double* pos = nullptr;                 // [W][P]  ensemble, updated in place
+    double* lnp = nullptr;                 // [W]
+    long long* accepted = nullptr;         // [W]
+    const int32_t* order = nullptr;        // [n_steps][W]       the block's random numbers, as mcd_stretch_move takes them
+    const double* zz = nullptr;            // [n_steps][2][W/2]
+    const double* thr = nullptr;           // [n_steps][2][W/2]
+    const int32_t* pick = nullptr;         // [n_steps][2][W/2]
+    double* chain = nullptr;               // [n_steps][W][P] or null
+    double* lnprob_chain = nullptr;        // [n_steps][W] or null
+    double* proposal = nullptr;            // [W/2][P]
+    uint8_t* ok = nullptr;                 // [W/2]   proposal inside the prior
+    int32_t* meta = nullptr;               // [META_WORDS]
+    double* table = nullptr;               // [W/2][k]   resolved parameter rows (the guard reads them back)
+    double* wpar = nullptr;                // [W/2][KD]  derived walker constants: what the main kernel reads
+};
+
+hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t acc_step, int acc_h, int64_t prop_step,
+                               int prop_h, const double* ll, double rerun_tag);
+hipError_t launch_stretch_status(hipStream_t s, const int32_t* meta, double* out);
 
 // background.SingleStars (mcd_kde.hip): slice plan and launch.  part_dmin / part_sum hold [n_slices][n] doubles.
 int kde_slices(int64_t n, int64_t m, int* slice_len);

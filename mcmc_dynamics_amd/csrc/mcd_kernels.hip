@@ -14,6 +14,7 @@
 // once per 64..256 walkers.  MFMA has nothing to offer here (no contraction).
 #include "mcd_internal.h"
 #include "mcd_math.h"
+#include "mcd_prep.h"
 
 namespace mcd {
 
@@ -24,7 +25,6 @@ constexpr int kBlock = 256;               // 4 waves: one per SIMD of a CU
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kPartialGroup = 8;            // walkers per group of the partial-sum array (8 doubles = one 64-byte segment)
 
-constexpr double kDeg2Rad = 0.017453292519943295769;
 constexpr double kR0Arcmin = 3437.7467707849392526;   // 10800 / pi, calc_xy_offset.py:11
 
 // ------------------------------------------------------------------------------------------------
@@ -82,39 +82,14 @@ __global__ __launch_bounds__(kBlock) void prepare_records_kernel(RawColumns raw,
 }
 
 // ------------------------------------------------------------------------------------------------
-// walker prep: resolved parameter rows (reference order) -> derived constants, one thread per row
+// walker prep: resolved parameter rows (reference order) -> derived constants, one thread per row (mcd_prep.h)
 template <class T>
 __global__ __launch_bounds__(kBlock) void prepare_walkers_kernel(const double* __restrict__ params, int64_t n_rows,
                                                                   int k, int model, int free_centre,
                                                                   T* __restrict__ wpar) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_rows) return;
-    const double* p = params + i * k;
-    T* w = wpar + i * KD;
-    // CONST:   v_sys, sigma_max, v_maxx, v_maxy [, ra_c, dec_c] [, v_back, sigma_back, f_back]
-    // PROFILE: v_sys, sigma_max, a, v_maxx, v_maxy, r_peak [, ra_c, dec_c] [, v_back, sigma_back, f_back | f_back]
-    const bool prof = is_profile(model);
-    const double sigma = p[1];
-    const double a = prof ? p[2] : 0.0, rp = prof ? p[5] : 0.0;
-    w[W_VSYS] = (T)p[0];
-    w[W_S2] = (T)(sigma * sigma);                                   // runner.py:261 (sigma_los * sigma_los)
-    w[W_VX] = (T)(prof ? p[3] : p[2]);
-    w[W_VY] = (T)(prof ? p[4] : p[3]);
-    w[W_A2] = (T)(a * a); w[W_S2A] = (T)(sigma * sigma * a); w[W_RP2] = (T)(rp * rp); w[W_2RP] = (T)(2.0 * rp);
-    w[15] = (T)0;
-    int j = prof ? 6 : 4;
-    double sac = 0, cac = 1, sdc = 0, cdc = 1;
-    if (free_centre) {
-        sincos(p[j] * kDeg2Rad, &sac, &cac);
-        sincos(p[j + 1] * kDeg2Rad, &sdc, &cdc);
-        j += 2;
-    }
-    w[W_SAC] = (T)sac; w[W_CAC] = (T)cac; w[W_SDC] = (T)sdc; w[W_CDC] = (T)cdc;
-    double vb = 0, sb = 0, fb = 0;
-    const int bg = bg_kind(model);
-    if (bg == BG_GAUSS) { vb = p[j]; sb = p[j + 1]; fb = p[j + 2]; }
-    else if (bg == BG_FIXED_DENSITY) { fb = p[j]; }
-    w[W_VB] = (T)vb; w[W_SB2] = (T)(sb * sb); w[W_FB] = (T)fb;
+    walker_constants<T>(params + i * k, model, free_centre != 0, wpar + i * KD);
 }
 
 __device__ const double kExpTabDevice[kExpTabSize] = {MCD_EXP_TABLE_VALUES};
@@ -212,9 +187,14 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
 
 // ------------------------------------------------------------------------------------------------
 // final reduction: one block per (parameter set, group of 8 walkers).  The group's partial sums are one contiguous
-// [chunk][8] array; thread t = (sublane s = t / 8, walker j = t % 8) adds the chunks c0 + s, c0 + s + SUB, ... in
-// four interleaved accumulators (four loads in flight), the SUB sublanes are combined by a wave shuffle tree and a
-// fixed-order sum over the waves: the order of every addition is fixed by (n_chunks, SUB) alone -- bitwise repeatable.
+// [chunk][8] array of 64-byte segments.  Thread t = (sublane s = t / 4, quarter q = t % 4) reads the 16 bytes of walkers
+// 2q, 2q + 1 of the chunks c0 + s, c0 + s + 2 SUB, ...: a wave's load covers sixteen whole segments (1 KiB, contiguous),
+// and kReduceUnroll independent accumulator pairs keep that many loads in flight per thread -- the kernel is bound by
+// memory latency (6 MB over 16..32 workgroups), and with 8-byte loads, four in flight, it took 6.5 us where this takes 3.
+// The sublanes are combined by a wave shuffle tree and a fixed-order sum over the waves: the order of every addition is
+// fixed by (n_chunks, SUB) alone -- bitwise repeatable.
+constexpr int kReduceUnroll = 8;
+
 template <int SUB>
 __global__ __launch_bounds__(kPartialGroup * SUB) void reduce_group_kernel(const double* __restrict__ partials,
                                                                             const int64_t* __restrict__ offs,
@@ -224,36 +204,62 @@ __global__ __launch_bounds__(kPartialGroup * SUB) void reduce_group_kernel(const
                                                                             double* __restrict__ out) {
     constexpr int kThreads = kPartialGroup * SUB;
     constexpr int kWaves = kThreads / kWave;
+    constexpr int kSublanes = kThreads / 4;
     __shared__ double lds[kWaves > 1 ? kWaves : 1][kPartialGroup];
     const int64_t pset = blockIdx.x / n_groups, g = blockIdx.x - pset * n_groups;
-    const int j = threadIdx.x & (kPartialGroup - 1), s = threadIdx.x >> 3;
+    const int q = threadIdx.x & 3, s = threadIdx.x >> 2;
     const int64_t c0 = offs[pset], c1 = offs[pset + 1];
-    const double* __restrict__ col = partials + g * n_chunks * kPartialGroup + j;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const double2* __restrict__ col = reinterpret_cast<const double2*>(partials + g * n_chunks * kPartialGroup) + q;
+    double2 a[kReduceUnroll];
+#pragma unroll
+    for (int u = 0; u < kReduceUnroll; ++u) a[u] = make_double2(0.0, 0.0);
     int64_t c = c0 + s;
-    for (; c + 3 * SUB < c1; c += 4 * SUB) {
-        a0 += col[c * kPartialGroup];
-        a1 += col[(c + SUB) * kPartialGroup];
-        a2 += col[(c + 2 * SUB) * kPartialGroup];
-        a3 += col[(c + 3 * SUB) * kPartialGroup];
-    }
-    for (; c < c1; c += SUB) a0 += col[c * kPartialGroup];
-    double acc = (a0 + a1) + (a2 + a3);
-    // the 8 sublanes of a wave: lanes j, j + 8, ..., j + 56
+    for (; c + (kReduceUnroll - 1) * kSublanes < c1; c += kReduceUnroll * kSublanes) {
 #pragma unroll
-    for (int off = 32; off >= kPartialGroup; off >>= 1) acc += __shfl_xor(acc, off, kWave);
-    if constexpr (kWaves > 1) {
-        if ((threadIdx.x & (kWave - 1)) < kPartialGroup) lds[threadIdx.x >> 6][j] = acc;
-        __syncthreads();
-        if (threadIdx.x < kPartialGroup) {
-            acc = lds[0][j];
-#pragma unroll
-            for (int w = 1; w < kWaves; ++w) acc += lds[w][j];
+        for (int u = 0; u < kReduceUnroll; ++u) {
+            const double2 v = col[(c + u * kSublanes) * 4];
+            a[u].x += v.x;
+            a[u].y += v.y;
         }
     }
-    const int64_t w = g * kPartialGroup + j;
-    if (threadIdx.x < kPartialGroup && w < n_walkers)
-        out[pset * n_walkers + w] = acc + (pset_const ? pset_const[pset] : 0.0);   // walker-independent part (sum of lnL_bg)
+#pragma unroll
+    for (int u = 0; u < kReduceUnroll; ++u) {
+        if (c < c1) {
+            const double2 v = col[c * 4];
+            a[u].x += v.x;
+            a[u].y += v.y;
+        }
+        c += kSublanes;
+    }
+    double ax = ((a[0].x + a[1].x) + (a[2].x + a[3].x)) + ((a[4].x + a[5].x) + (a[6].x + a[7].x));
+    double ay = ((a[0].y + a[1].y) + (a[2].y + a[3].y)) + ((a[4].y + a[5].y) + (a[6].y + a[7].y));
+    static_assert(kReduceUnroll == 8, "the combining tree above is written for eight accumulators");
+    // the 16 sublanes of a wave: lanes q, q + 4, ..., q + 60
+#pragma unroll
+    for (int off = 32; off >= 4; off >>= 1) {
+        ax += __shfl_xor(ax, off, kWave);
+        ay += __shfl_xor(ay, off, kWave);
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    if constexpr (kWaves > 1) {
+        if (lane < 4) { lds[threadIdx.x >> 6][2 * q] = ax; lds[threadIdx.x >> 6][2 * q + 1] = ay; }
+        __syncthreads();
+        if (threadIdx.x < kPartialGroup) {
+            double acc = lds[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) acc += lds[w][threadIdx.x];
+            const int64_t w = g * kPartialGroup + threadIdx.x;
+            if (w < n_walkers) out[pset * n_walkers + w] = acc + (pset_const ? pset_const[pset] : 0.0);
+        }
+    } else {
+        // one wave: lanes 0..3 hold the sums of walkers (2q, 2q + 1)
+        if (lane < 4) {
+            const int64_t w = g * kPartialGroup + 2 * q;
+            const double add = pset_const ? pset_const[pset] : 0.0;      // walker-independent part (sum of lnL_bg)
+            if (w < n_walkers) out[pset * n_walkers + w] = ax + add;
+            if (w + 1 < n_walkers) out[pset * n_walkers + w + 1] = ay + add;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

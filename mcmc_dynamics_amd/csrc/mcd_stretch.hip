@@ -1,0 +1,403 @@
+// mcd_stretch.hip -- the stretch move of mcd_stretch.h with the ensemble resident on the device.
+//
+// The host-driven block (mcd_stretch.h) spends ~45 us per half step between two kernels: wait for the sums, accept,
+// propose, range guard, upload, two launches.  With 1e6 stars x 128 walkers the kernel itself takes ~107 us, so a third
+// of the device time is idle.  Here the positions, their log-probabilities and the block's random numbers live on the
+// device, and ONE small kernel per half step does what the host loop does between two evaluations:
+//
+//     accept / reject the previous half step  ->  [end of a step: chain row]  ->  propose the next half step,
+//     box prior, resolved parameter rows, derived walker constants, range guard of the new table
+//
+// so a whole block of steps is a chain of launches (step kernel, main kernel, reduction [, all-reduce]) that the host
+// enqueues ahead and waits for once.  The arithmetic is the host loop's, operation for operation (no FMA contraction:
+// -ffp-contract=off), the walker constants come from the same device function as the prep kernel's (mcd_prep.h) and the
+// range guard is the same code (mcd_guard.h): the chain is bit-identical to the host-driven one.
+//
+// What the device cannot decide alone it only detects: a NaN sum, a re-run request of the fast mixture kernels, a table
+// whose guard verdict differs from the kernel family the host enqueued, a half step with no proposal inside the prior.
+// Each sets a bit in the status word; the host then discards the block and runs it through the host-driven loop from the
+// same inputs (mcd_api.hip: mcd_stretch_move), which handles all of them.
+#include "mcd_internal.h"   // first: <hip/hip_runtime.h> before the MCD_HD headers
+#include "mcd_guard.h"
+#include "mcd_math.h"
+#include "mcd_prep.h"
+
+namespace mcd {
+
+namespace {
+
+constexpr int kStepBlock = 256;
+
+#ifdef MCD_CHAIN_STAMPS
+#define MCD_STAMP(k) do { if (threadIdx.x == 0 && d.stamps) d.stamps[d.launch_index * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MCD_STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ double wave_lesser(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = ParamRanges::lesser(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ double wave_greater(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = ParamRanges::greater(v, __shfl_xor(v, off));
+    return v;
+}
+
+__device__ __forceinline__ void wave_merge(ParamRanges& r) {
+    r.s2_min = wave_lesser(r.s2_min); r.s2_max = wave_greater(r.s2_max); r.amp = wave_greater(r.amp);
+    r.sb2_min = wave_lesser(r.sb2_min); r.sb2_max = wave_greater(r.sb2_max);
+    r.f_min = wave_lesser(r.f_min); r.f_max = wave_greater(r.f_max);
+    r.len_min = wave_lesser(r.len_min); r.len_max = wave_greater(r.len_max);
+    r.finite = __all(r.finite ? 1 : 0) != 0;
+}
+
+// the quantities the model has (the others keep their initial values in every lane: nothing to exchange)
+__device__ __forceinline__ void wave_merge_for(ParamRanges& r, int model) {
+    r.s2_min = wave_lesser(r.s2_min); r.s2_max = wave_greater(r.s2_max); r.amp = wave_greater(r.amp);
+    const int bg = bg_kind(model);
+    if (bg == BG_GAUSS) { r.sb2_min = wave_lesser(r.sb2_min); r.sb2_max = wave_greater(r.sb2_max); }
+    if (bg == BG_GAUSS || bg == BG_FIXED_DENSITY) { r.f_min = wave_lesser(r.f_min); r.f_max = wave_greater(r.f_max); }
+    if (is_profile(model)) { r.len_min = wave_lesser(r.len_min); r.len_max = wave_greater(r.len_max); }
+    r.finite = __all(r.finite ? 1 : 0) != 0;
+}
+
+__device__ __forceinline__ void store_ranges(const ParamRanges& r, double* o) {
+    o[0] = r.s2_min; o[1] = r.s2_max; o[2] = r.amp; o[3] = r.sb2_min; o[4] = r.sb2_max; o[5] = r.f_min; o[6] = r.f_max;
+    o[7] = r.len_min; o[8] = r.len_max; o[9] = r.finite ? 1.0 : 0.0;
+}
+__device__ __forceinline__ ParamRanges load_ranges(const double* o) {
+    ParamRanges r;
+    r.s2_min = o[0]; r.s2_max = o[1]; r.amp = o[2]; r.sb2_min = o[3]; r.sb2_max = o[4]; r.f_min = o[5]; r.f_max = o[6];
+    r.len_min = o[7]; r.len_max = o[8]; r.finite = o[9] != 0.0;
+    return r;
+}
+
+// One workgroup.  acc_step >= 0: accept / reject half step (acc_step, acc_h) from the sums `ll` (written by the reduction
+// [+ all-reduce] that precedes this launch on the stream).  prop_step >= 0: propose half step (prop_step, prop_h).
+__global__ __launch_bounds__(kStepBlock) void stretch_step_kernel(StretchDevice d, int64_t acc_step, int acc_h,
+                                                                   int64_t prop_step, int prop_h,
+                                                                   const double* __restrict__ ll, double rerun_tag) {
+    const int64_t W = d.n_walkers, half = W / 2;
+    const int P = d.n_dim, K = d.k;
+    const int tid = threadIdx.x;
+    __shared__ int s_n_ok, s_donor;
+    __shared__ double s_ranges[kStepBlock / 64][10];          // ParamRanges of each wave (a type with initialisers cannot be __shared__)
+
+    if (acc_step >= 0) {
+        const int32_t* first = d.order + acc_step * W + (acc_h == 0 ? 0 : half);
+        const double* t = d.thr + (acc_step * 2 + acc_h) * half;
+        const int n_ok = d.meta[META_N_OK];
+        // single device: the fast mixture kernels write the launch's tag behind the sums when they want the plain kernels
+        if (tid == 0 && rerun_tag != 0.0 && ll[half] == rerun_tag) atomicOr(&d.meta[META_STATUS], CHAIN_RERUN);
+        for (int64_t j = tid; j < half; j += kStepBlock) {
+            const double new_lnp = (n_ok > 0 && d.ok[j]) ? ll[j] : -kInfinity;
+            if (new_lnp != new_lnp) atomicOr(&d.meta[META_STATUS], CHAIN_NAN);   // genuine, or the multi-rank re-run signal
+            const int64_t w = first[j];
+            if (t[j] < new_lnp - d.lnp[w]) {                                     // accept iff thr < new_lnp - old_lnp
+                const double* p = d.proposal + j * P;
+                for (int c = 0; c < P; ++c) d.pos[w * P + c] = p[c];
+                d.lnp[w] = new_lnp;
+                d.accepted[w] += 1;
+            }
+        }
+        __syncthreads();
+        if (acc_h == 1) {
+            if (d.chain) for (int64_t x = tid; x < W * P; x += kStepBlock) d.chain[acc_step * W * P + x] = d.pos[x];
+            if (d.lnprob_chain) for (int64_t w = tid; w < W; w += kStepBlock) d.lnprob_chain[acc_step * W + w] = d.lnp[w];
+        }
+    }
+    if (prop_step < 0) return;
+
+    const int32_t* first = d.order + prop_step * W + (prop_h == 0 ? 0 : half);
+    const int32_t* second = d.order + prop_step * W + (prop_h == 0 ? half : 0);
+    const double* z = d.zz + (prop_step * 2 + prop_h) * half;
+    const int32_t* pk = d.pick + (prop_step * 2 + prop_h) * half;
+    if (tid == 0) { s_n_ok = 0; s_donor = 0x7fffffff; }
+    __syncthreads();
+    // proposal = partner - (partner - s) * z, inside the inclusive box prior (false for NaN)
+    for (int64_t j = tid; j < half; j += kStepBlock) {
+        const double* s = d.pos + (int64_t)first[j] * P;
+        const double* q = d.pos + (int64_t)second[pk[j]] * P;
+        double* p = d.proposal + j * P;
+        bool good = d.fixed_ok != 0;
+        for (int c = 0; c < P; ++c) {
+            const double v = q[c] - (q[c] - s[c]) * z[j];
+            p[c] = v;
+            good = good && (v >= d.lo[c]) && (v <= d.hi[c]);
+        }
+        d.ok[j] = good;
+        if (good) { atomicAdd(&s_n_ok, 1); atomicMin(&s_donor, (int)j); }
+    }
+    __syncthreads();
+    const int n_ok = s_n_ok, donor = s_donor;
+    ParamRanges mine;
+    if (n_ok > 0) {
+        // rows outside the prior take the first valid row's place in the launch and are masked when the sums come back
+        for (int64_t j = tid; j < half; j += kStepBlock) {
+            const double* p = d.proposal + (d.ok[j] ? j : (int64_t)donor) * P;
+            double* row = d.table + j * K;
+            for (int c = 0; c < K; ++c) {
+                const int src = d.col_source[c];
+                row[c] = src < 0 ? d.col_const[c] : (d.col_factor[c] == 1.0 ? p[src] : p[src] * d.col_factor[c]);
+            }
+            walker_constants<double>(row, d.model, d.free_centre != 0, d.wpar + j * KD);
+            mine.add_row(row, K, d.model, d.free_centre != 0);
+        }
+    }
+    wave_merge(mine);
+    if ((tid & 63) == 0) store_ranges(mine, s_ranges[tid >> 6]);
+    __syncthreads();
+    if (tid == 0) {
+        d.meta[META_N_OK] = n_ok;
+        if (n_ok == 0) {
+            atomicOr(&d.meta[META_STATUS], CHAIN_NO_PROPOSAL);
+        } else {
+            ParamRanges all = load_ranges(s_ranges[0]);
+            for (int i = 1; i < kStepBlock / 64; ++i) all.merge(load_ranges(s_ranges[i]));
+            int level = 0;
+            if (d.allow_fast) {
+                level = level_verdict(d.stats, d.model, false, half, all);
+                if (d.allow_fast == 2 && level > 1) level = 1;
+            }
+            if (level != d.expected_level) {
+                if (!(d.meta[META_STATUS] & CHAIN_LEVEL)) d.meta[META_LEVEL] = level;   // the first verdict that differed
+                atomicOr(&d.meta[META_STATUS], CHAIN_LEVEL);
+            }
+        }
+    }
+}
+
+// The same step for ensembles whose positions fit into LDS (every shipped configuration: W x P x 8 bytes <= 32 KiB,
+// W <= 2 x kStepBlock, <= 12 columns): one proposal per thread, held in registers.  The general kernel above is written
+// like the host loop and the compiler has to keep its loads in program order (stores to pos / lnp may alias them): ~16
+// dependent trips to memory, and the memory is far away -- the sums were written by workgroups on other XCDs.  This one
+// is built around what a single-workgroup kernel between two 105 us main kernels pays for (measured by cutting it short
+// phase by phase, 1e6 stars x 128 walkers per half step):
+//   * memory round trips: ONE round of loads brings in everything (positions, log-probabilities, the sums, the previous
+//     proposals, the random numbers of both half steps); the indirections (lnp[first], second[pick], the pair's
+//     positions) are LDS reads; results leave in one round of stores;
+//   * instruction fetch: the code runs once per launch from a cold instruction cache and costs ~1 us per KiB of
+//     straight-line code it executes (a version with every column loop unrolled to 12 spent 8 of its 12 us there, for 4
+//     columns in use; rolled loops over LDS rows are worse still: every iteration waits out an LDS round trip).  Hence
+//     MAXC, the unroll bound of the column loops, is a template parameter (4, 8 or 12, the smallest that holds n_dim and
+//     k), and the guard's range reduction skips the quantities the model does not have.
+// Same operations on the same numbers as the general kernel and the host loop, same results.
+constexpr int kSmallPosBytes = 32 << 10;
+
+extern __shared__ double s_dynamic[];     // [W * P] positions | [W] log-probabilities | [W / 2] int32: the partner half
+
+template <int kMaxCols>
+__global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchDevice d, int64_t acc_step, int acc_h,
+                                                                         int64_t prop_step, int prop_h,
+                                                                         const double* __restrict__ ll, double rerun_tag) {
+    const int half = (int)(d.n_walkers / 2), W = 2 * half, P = d.n_dim, K = d.k;
+    const int j = threadIdx.x;
+    const bool active = j < half, do_acc = acc_step >= 0, do_prop = prop_step >= 0;
+    __shared__ int s_wave_ok[kStepBlock / 64], s_wave_first[kStepBlock / 64];
+    __shared__ double s_ranges[kStepBlock / 64][10];
+    __shared__ double s_donor_prop[kMaxCols];
+    __shared__ double s_lo[kMaxCols], s_hi[kMaxCols], s_const[kMaxCols], s_factor[kMaxCols];
+    __shared__ int s_source[kMaxCols];
+    __shared__ double s_rows[kStepBlock][kMaxCols + 1];        // (+1: rows of different threads start in different banks)
+    double* const s_pos = s_dynamic;
+    double* const s_lnp = s_dynamic + W * P;
+    int* const s_second = reinterpret_cast<int*>(s_lnp + W);
+
+    MCD_STAMP(0);
+    // ---- the one round of loads: nothing here depends on this kernel's own stores ----
+    // (all loads of the copy first, then the LDS stores: a plain copy loop of unknown trip count is compiled to one
+    // round trip per iteration, 3.5 us for the four iterations of 256 walkers x 4 columns)
+    {
+        constexpr int kPairs = kSmallPosBytes / 16 / kStepBlock;          // double2 loads per thread that cover the largest ensemble
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(d.pos);
+        const int n_pairs = W * P / 2;                                     // (W is even)
+        double2 r[kPairs];
+#pragma unroll
+        for (int u = 0; u < kPairs; ++u) {
+            const int x = j + u * kStepBlock;
+            r[u] = x < n_pairs ? src[x] : make_double2(0.0, 0.0);
+        }
+        const double l0 = j < W ? d.lnp[j] : 0.0, l1 = j + kStepBlock < W ? d.lnp[j + kStepBlock] : 0.0;
+#pragma unroll
+        for (int u = 0; u < kPairs; ++u) {
+            const int x = j + u * kStepBlock;
+            if (x < n_pairs) { s_pos[2 * x] = r[u].x; s_pos[2 * x + 1] = r[u].y; }
+        }
+        if (j < W) s_lnp[j] = l0;
+        if (j + kStepBlock < W) s_lnp[j + kStepBlock] = l1;
+    }
+    int n_ok_prev = 0, w_acc = 0;
+    bool ok_prev = false;
+    double ll_j = 0.0, thr_j = 0.0, flag_word = 0.0;
+    double prev[kMaxCols];
+    if (do_acc) {
+        n_ok_prev = d.meta[META_N_OK];
+        if (j == 0 && rerun_tag != 0.0) flag_word = ll[half];
+        if (active) {
+            ok_prev = d.ok[j] != 0;
+            ll_j = ll[j];
+            w_acc = d.order[acc_step * W + (acc_h == 0 ? 0 : half) + j];
+            thr_j = d.thr[(acc_step * 2 + acc_h) * half + j];
+#pragma unroll
+            for (int c = 0; c < kMaxCols; ++c) prev[c] = c < P ? d.proposal[j * P + c] : 0.0;
+        }
+    }
+    int w_s = 0, pick_j = 0;
+    double z_j = 0.0;
+    if (do_prop && active) {
+        w_s = d.order[prop_step * W + (prop_h == 0 ? 0 : half) + j];
+        s_second[j] = d.order[prop_step * W + (prop_h == 0 ? half : 0) + j];
+        pick_j = d.pick[(prop_step * 2 + prop_h) * half + j];
+        z_j = d.zz[(prop_step * 2 + prop_h) * half + j];
+    }
+    if (do_prop && j < kMaxCols) {
+        s_lo[j] = j < P ? d.lo[j] : 0.0;
+        s_hi[j] = j < P ? d.hi[j] : 0.0;
+        s_source[j] = j < K ? d.col_source[j] : -1;
+        s_const[j] = j < K ? d.col_const[j] : 0.0;
+        s_factor[j] = j < K ? d.col_factor[j] : 1.0;
+    }
+    __syncthreads();
+    MCD_STAMP(1);
+    // ---- accept / reject (walkers of one half step are distinct: no two threads touch the same row) ----
+    if (do_acc) {
+        if (j == 0 && rerun_tag != 0.0 && flag_word == rerun_tag) atomicOr(&d.meta[META_STATUS], CHAIN_RERUN);
+        if (active) {
+            const double new_lnp = (n_ok_prev > 0 && ok_prev) ? ll_j : -kInfinity;
+            if (new_lnp != new_lnp) atomicOr(&d.meta[META_STATUS], CHAIN_NAN);
+            if (thr_j < new_lnp - s_lnp[w_acc]) {
+#pragma unroll
+                for (int c = 0; c < kMaxCols; ++c)
+                    if (c < P) { s_pos[w_acc * P + c] = prev[c]; d.pos[w_acc * P + c] = prev[c]; }
+                s_lnp[w_acc] = new_lnp;
+                d.lnp[w_acc] = new_lnp;
+                atomicAdd((unsigned long long*)&d.accepted[w_acc], 1ull);
+            }
+        }
+        __syncthreads();                              // the ensemble is final for this half step
+        if (acc_h == 1) {
+            if (d.chain) for (int x = j; x < W * P; x += kStepBlock) d.chain[acc_step * W * P + x] = s_pos[x];
+            if (d.lnprob_chain) for (int w = j; w < W; w += kStepBlock) d.lnprob_chain[acc_step * W + w] = s_lnp[w];
+        }
+    }
+    MCD_STAMP(2);
+    if (!do_prop) return;
+    // ---- propose ----
+    bool good = false;
+    double mine_prop[kMaxCols];
+    if (active) {
+        const int w_q = s_second[pick_j];
+        good = d.fixed_ok != 0;
+#pragma unroll
+        for (int c = 0; c < kMaxCols; ++c) {
+            if (c < P) {
+                const double sc = s_pos[w_s * P + c], qc = s_pos[w_q * P + c];
+                const double v = qc - (qc - sc) * z_j;
+                mine_prop[c] = v;
+                d.proposal[j * P + c] = v;
+                good = good && (v >= s_lo[c]) && (v <= s_hi[c]);
+            } else {
+                mine_prop[c] = 0.0;
+            }
+        }
+        d.ok[j] = good;
+    }
+    // how many proposals lie inside the prior, and the first of them: one ballot per wave (LDS atomics of 64 lanes on
+    // one address are served lane by lane: 2.5 us for the two of them)
+    {
+        const unsigned long long inside = __ballot(good ? 1 : 0);
+        if ((j & 63) == 0) {
+            s_wave_ok[j >> 6] = __popcll(inside);
+            s_wave_first[j >> 6] = inside ? j + __ffsll((long long)inside) - 1 : 0x7fffffff;
+        }
+    }
+    MCD_STAMP(3);
+    __syncthreads();
+    int n_ok = 0, donor = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < kStepBlock / 64; ++i) {
+        n_ok += s_wave_ok[i];
+        donor = s_wave_first[i] < donor ? s_wave_first[i] : donor;
+    }
+    if (j == donor) {
+#pragma unroll
+        for (int c = 0; c < kMaxCols; ++c) s_donor_prop[c] = mine_prop[c];
+    }
+    __syncthreads();
+    MCD_STAMP(4);
+    ParamRanges mine;
+    if (active && n_ok > 0) {
+        // a row outside the prior takes the first valid row's place in the launch and is masked when the sums come back
+        double* row = s_rows[j];
+#pragma unroll
+        for (int c = 0; c < kMaxCols; ++c) row[c] = good ? mine_prop[c] : s_donor_prop[c];          // (the proposal, for now)
+        double resolved[kMaxCols];
+#pragma unroll
+        for (int c = 0; c < kMaxCols; ++c) {
+            const int src = s_source[c];
+            const double pv = row[src < 0 ? 0 : src];
+            resolved[c] = src < 0 ? s_const[c] : (s_factor[c] == 1.0 ? pv : pv * s_factor[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxCols; ++c) {
+            row[c] = resolved[c];
+            if (c < K) d.table[j * K + c] = resolved[c];
+        }
+        walker_constants<double>(row, d.model, d.free_centre != 0, d.wpar + j * KD);
+        mine.add_row(row, K, d.model, d.free_centre != 0);
+    }
+    MCD_STAMP(5);
+    wave_merge_for(mine, d.model);
+    if ((j & 63) == 0) store_ranges(mine, s_ranges[j >> 6]);
+    __syncthreads();
+    MCD_STAMP(6);
+    if (j == 0) {
+        d.meta[META_N_OK] = n_ok;
+        if (n_ok == 0) {
+            atomicOr(&d.meta[META_STATUS], CHAIN_NO_PROPOSAL);
+        } else {
+            ParamRanges all = load_ranges(s_ranges[0]);
+            for (int i = 1; i < kStepBlock / 64; ++i) all.merge(load_ranges(s_ranges[i]));
+            int level = 0;
+            if (d.allow_fast) {
+                level = level_verdict(d.stats, d.model, false, half, all);
+                if (d.allow_fast == 2 && level > 1) level = 1;
+            }
+            if (level != d.expected_level) {
+                if (!(d.meta[META_STATUS] & CHAIN_LEVEL)) d.meta[META_LEVEL] = level;
+                atomicOr(&d.meta[META_STATUS], CHAIN_LEVEL);
+            }
+        }
+    }
+    MCD_STAMP(7);
+}
+
+// status word -> a double every rank can sum (multi-rank: ranks hold different catalogue statistics, so their guard
+// verdicts may differ; all of them must discard the block if one does)
+__global__ void stretch_status_kernel(const int32_t* meta, double* out) { out[0] = meta[META_STATUS] != 0 ? 1.0 : 0.0; }
+
+}  // namespace
+
+hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t acc_step, int acc_h, int64_t prop_step,
+                               int prop_h, const double* ll, double rerun_tag) {
+    const size_t pos_bytes = (size_t)d.n_walkers * d.n_dim * sizeof(double);
+    const size_t lds = pos_bytes + (size_t)d.n_walkers * sizeof(double) + (size_t)(d.n_walkers / 2) * sizeof(int32_t);
+    const int cols = d.k > d.n_dim ? d.k : d.n_dim;
+    const bool small = d.n_walkers <= 2 * kStepBlock && cols <= 12 && pos_bytes <= (size_t)kSmallPosBytes && !d.force_general;
+    if (small && cols <= 4)
+        hipLaunchKernelGGL(stretch_step_small_kernel<4>, dim3(1), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+    else if (small && cols <= 8)
+        hipLaunchKernelGGL(stretch_step_small_kernel<8>, dim3(1), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+    else if (small)
+        hipLaunchKernelGGL(stretch_step_small_kernel<12>, dim3(1), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+    else
+        hipLaunchKernelGGL(stretch_step_kernel, dim3(1), dim3(kStepBlock), 0, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+    return hipGetLastError();
+}
+
+hipError_t launch_stretch_status(hipStream_t s, const int32_t* meta, double* out) {
+    hipLaunchKernelGGL(stretch_status_kernel, dim3(1), dim3(1), 0, s, meta, out);
+    return hipGetLastError();
+}
+
+}  // namespace mcd

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
         (any_fn)mcd_last_error, (any_fn)mcd_abi_version, (any_fn)mcd_last_kernel_ms,
         (any_fn)mcd_last_device_ms, (any_fn)mcd_set_option, (any_fn)mcd_timing_collect,
         (any_fn)mcd_rerun_count, (any_fn)mcd_last_fast_level, (any_fn)mcd_last_launch_info,
-        (any_fn)mcd_ctx_comm_info, (any_fn)mcd_stretch_move};
+        (any_fn)mcd_ctx_comm_info, (any_fn)mcd_stretch_move, (any_fn)mcd_stretch_info};
     size_t i;
     double out[3] = {0.0, 0.0, 0.0};
     for (i = 0; i < sizeof table / sizeof table[0]; ++i) CHECK(table[i] != NULL);
@@ -42,6 +42,7 @@ int main(int argc, char** argv) {
     CHECK(mcd_last_fast_level(NULL) == -1);
     CHECK(mcd_ctx_comm_info(NULL, NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_stretch_move(NULL, NULL, 1, out, out, NULL, out, out, NULL, NULL, NULL, NULL) != MCD_OK);
+    CHECK(mcd_stretch_info(NULL, NULL, NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_catalog_destroy(NULL) == MCD_OK);
     CHECK(mcd_ctx_destroy(NULL) == MCD_OK);
     printf("abi %d: %d entry points link from C\n", mcd_abi_version(), (int)(sizeof table / sizeof table[0]));
@@ -91,6 +92,11 @@ int main(int argc, char** argv) {
             CHECK(mcd_stretch_move(cat, &sd, 1, &pos[0][0], lnp, order, zz, thr, pick, chain, lnpc, acc) == MCD_OK);
             CHECK(acc[0] == 1 && acc[1] == 1 && fabs(lnpc[0] - want[0]) < 1e-13 && fabs(lnpc[1] - want[1]) < 1e-13);
             CHECK(chain[1] == 3.0 && chain[5] == 7.5);
+            {
+                int64_t on_device = -1, on_host = -1, discarded = -1;
+                CHECK(mcd_stretch_info(cat, &on_device, &on_host, &discarded, NULL) == MCD_OK);
+                CHECK(on_device + on_host == 1 && discarded <= on_host);
+            }
             order[1] = 7;                                                       /* an index outside the ensemble */
             CHECK(mcd_stretch_move(cat, &sd, 1, &pos[0][0], lnp, order, zz, thr, pick, chain, lnpc, acc) == MCD_ERR_INVALID);
             CHECK(mcd_ctx_comm_info(ctx, &comm_size, &comm_rank, &version) == MCD_OK && comm_size == 0 && comm_rank == -1);
