@@ -158,6 +158,27 @@ def rank_mode():
     sampler = fit(n_walkers=32, n_steps=12, pos=pos if rank == 0 else pos + 1.0, prefix=None)    # only rank 0's start counts
     chain = np.asarray(sampler.chain)
     assert group.same_everywhere(chain) and np.all(np.isfinite(sampler.lnprobability))
+    # the blocks ran resident on every rank's device (csrc/mcd_stretch.hip: sums and the block's status word through the
+    # all-reduce), and the host-driven loop gives the same chain bit for bit on this rank's shard sums
+    info = fit._catalog.stretch_info()
+    assert info["device_blocks"] >= 1 and info["discarded_blocks"] == 0, info
+    rng = np.random.default_rng(77)                                   # (the same numbers on every rank)
+    order = np.argsort(rng.random((9, 32)), axis=1).astype(np.int32)
+    u = rng.random((9, 4, 16))
+    zz = np.ascontiguousarray((u[:, :2] + 1.0) ** 2 / 2.0)
+    thr = np.ascontiguousarray(np.log(u[:, 2:]) - 3.0 * np.log(zz))
+    pick = rng.integers(0, 16, size=(9, 2, 16)).astype(np.int32)
+    start, lnp0 = np.ascontiguousarray(chain[:, -1, :]), np.ascontiguousarray(np.asarray(sampler.lnprobability)[:, -1])
+    blocks = []
+    for mode in (1, 0):
+        fit._catalog.set_option("device_chain", mode)
+        p, l, c = start.copy(), lnp0.copy(), np.empty((9, 32, 4))
+        fit._catalog.stretch_move(fit._stretch_plan(), p, l, order, zz, thr, pick, c, None, None)
+        blocks.append((p, l, c))
+    fit._catalog.set_option("device_chain", 1)
+    assert all(np.array_equal(a, b) for a, b in zip(*blocks)) and group.same_everywhere(blocks[0][2])
+    after = fit._catalog.stretch_info()
+    assert after["device_blocks"] == info["device_blocks"] + 1 and after["host_blocks"] == info["host_blocks"] + 1, after
     full = ConstantFit(DataReader(cols), background=Gaussian(20.0, 40.0), context=one)
     full.parameters["ra_center"].set(value=CENTRE[0], fixed=True)
     full.parameters["dec_center"].set(value=CENTRE[1], fixed=True)
