@@ -543,6 +543,7 @@ def main():
     result = gpu_cat.fetch()
     info = gpu_cat.launch_info()
     info["kernel_family"] = {0: "plain", 1: "fast", 2: "fast, narrow-range variant", -1: "none"}[gpu_cat.fast_level]
+    info["prefetch"] = gpu_cat.last_prefetch             # 1: the instantiation that prefetches the next iteration's records
 
     # blocking C-ABI call (host params in, host results out): the PCIe/sync-inclusive rate, never `value`
     n_sync = max(20, min(50, args.steps))
@@ -635,6 +636,10 @@ def main():
             (model + "_general" if model in ("bgfixed", "bggauss") else model)
         row, src = isa_counts(isa_key)
         if row is not None:
+            # the instantiation the timed launches ran: with or without the software prefetch of the records
+            prefetching = info.get("prefetch") == 1
+            if prefetching and "valu_per_term_prefetch" in row:
+                row = dict(row, valu_per_term=row["valu_per_term_prefetch"], f64_per_term=row["f64_per_term_prefetch"])
             achieved = row["valu_per_term"] * local_terms / 64.0 / kernel_s
             roofline = {
                 "bound": "valu_f64", "achieved": achieved, "peak": VALU_F64_PEAK, "unit": "VALU wave-instructions/s",
@@ -642,7 +647,7 @@ def main():
                 "kernel": "mcd::loglike_kernel", "kernel_us": kernel_s * 1e6, "kernel_us_sampled_launches": t["kernel_samples"],
                 "kernel_us_first_20_launches_after_idle": t["cold_kernel_us"],
                 "valu_per_term": row["valu_per_term"], "valu_f64_per_term": row["f64_per_term"],
-                "valu_per_term_source": src, "terms_per_launch": local_terms,
+                "prefetching_instantiation": prefetching, "valu_per_term_source": src, "terms_per_launch": local_terms,
                 "peak_definition": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 vector instruction",
                 "hbm_streaming_model": {"algorithmic_bytes_per_term": bytes_per_term, "GBps": streaming_gbps,
                                         "frac_of_8TBps": streaming_gbps / HBM_PEAK_GBPS,

@@ -245,10 +245,12 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *                      than a fraction of a millisecond (default 20000; 0: always block)
  *   "device_chain"  1 (default): mcd_stretch_move keeps the ensemble resident on the device where it can (see there);
  *                      0: host-driven blocks only
- *   "prefetch"      software prefetch of the star records of the next loop iteration: -1 (default) on for devices whose
- *                      share of the catalogue is at least 8 MiB of records (it hides the memory latency there, +1 % at
- *                      256 walkers to +45 % at 64 on 1e6 stars) and off below (the records stay in the caches; the
- *                      prefetch costs ~5 % there); 0 off, 1 on.  Results do not depend on it.
+ *   "prefetch"      software prefetch of the star records of the next loop iteration (a second instantiation of the fast
+ *                      kernels): -1 (default) by shape -- mixture models from 8 MiB of records per device up (it hides
+ *                      the memory latency there: +8 % at 256 walkers to +45 % at 64 on 1e6 stars), models without
+ *                      background only for un-binned catalogues from 128 MiB up (their 16-star loop hides the latency
+ *                      itself; the prefetch costs binned and many-walker shapes 3 - 6 %); 0 off, 1 on.  Results do not
+ *                      depend on it.
  *   "target_waves"  number of waves the chunking aims for per device (default 10240)
  *   "chunk_len"     explicit nominal chunk length in stars (rounded up to a multiple of 32; 0, the default: derived from
  *                      "target_waves"); tuning aid
@@ -265,6 +267,10 @@ int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_lau
  * f_back == 0 or density == 0 that lies > 37 sigma from the only remaining component.  Only the literal expression
  * reproduces the reference's value there; the re-evaluation is automatic and synchronous inside fetch / batch. */
 int64_t mcd_rerun_count(const mcd_catalog* cat);
+/* 1 when the most recent main-kernel launch used the instantiation that prefetches the next loop iteration's star records
+ * (option "prefetch"), 0 when not, -1 before the first launch.  The harness picks the per-term instruction count of the
+ * roofline by it (csrc/isa_mix.json holds both instantiations). */
+int mcd_last_prefetch(const mcd_catalog* cat);
 /* Kernel family the range guard chose for the batch staged last: 0 plain, 1 fast formulation, 2 narrow-range variant of
  * the mixture kernels (no per-star exponent bookkeeping; chunks holding a star outside its domain -- a certain member, an
  * extreme background likelihood, an empty component -- still run the fast formulation); -1 before any call. */

@@ -58,6 +58,7 @@ SYMBOLS = {
     "mcd_last_device_ms": (ctypes.c_double, [ctypes.c_void_p]),
     "mcd_timing_collect": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_int64_p]),
     "mcd_rerun_count": (ctypes.c_int64, [ctypes.c_void_p]),
+    "mcd_last_prefetch": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_last_fast_level": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "mcd_last_launch_info": (ctypes.c_int, [ctypes.c_void_p, _c_int64_p, ctypes.POINTER(ctypes.c_int32), _c_int64_p,
@@ -370,6 +371,11 @@ class Catalog(object):
                                        accepted.ctypes.data_as(_c_int64_p) if accepted is not None else None)
         _check(self.lib, rc, "mcd_stretch_move")
         self._walkers = w // 2
+
+    @property
+    def last_prefetch(self):
+        """1 / 0: the last main-kernel launch used / did not use the record-prefetching instantiation; -1 before any launch."""
+        return self.lib.mcd_last_prefetch(self.handle)
 
     def stretch_info(self):
         """Where the blocks of ``stretch_move`` ran: {'device_blocks', 'host_blocks', 'discarded_blocks', 'last_discard_status'}

@@ -206,6 +206,7 @@ struct mcd_catalog {
     int chain_consecutive = 0;         // discarded blocks in a row (the back-off doubles with each)
     int64_t chain_device_blocks = 0, chain_host_blocks = 0, chain_discarded = 0;
     int chain_last_status = 0;         // status word of the last discarded block (mcd::ChainStatus bits)
+    int last_prefetch = -1;            // the last main-kernel launch used the prefetching instantiation (-1: none yet)
 };
 
 namespace {
@@ -341,6 +342,21 @@ int fast_level(const mcd_catalog* cat, const double* params, int64_t n_rows) {
     return cat->allow_fast == 2 && level > 1 ? 1 : level;
 }
 
+// Which launches use the prefetching instantiation of the main kernel (mcd_math.h: RecordPrefetch; option "prefetch").
+// Measured per shape with the prefetch compiled in and out (1x MI355X, us per step, in / out):
+//   mixtures   C3 bgfixed 1e6 x 256: 201 / 217    x 128: 107 / 117    x 64: 62 / 90    bggauss 1e6 x 256: 370 / 381
+//   CONST      1e6 x 256: 77.0 / 76.4   x 512: 148 / 144   x 128: 46.4 / 46.9   C5 (55 bins x 512): 173 / 164
+//              C5 x 256: 94 / 90        C4 1e7 x 256: 694 / 711                  C2 1e5 x 256: 17.0 / 16.1
+// The mixture loops wait for their records (4 stars per iteration, a third of the instructions are one dependent chain);
+// the fraction tree of the no-background models reads 16 stars per iteration and hides the latency by itself, so the
+// prefetch only pays there when the catalogue is far beyond every cache (C4).
+bool wants_prefetch(const mcd_catalog* cat, const Shard& sh) {
+    if (cat->prefetch >= 0) return cat->prefetch != 0;
+    const size_t bytes = (size_t)sh.n * (size_t)mcd::record_bytes(cat->model, cat->free_centre, cat->precision);
+    if (mcd::bg_kind(cat->model) == mcd::BG_NONE) return cat->n_psets == 1 && bytes >= ((size_t)128 << 20);
+    return bytes >= ((size_t)8 << 20);
+}
+
 int stage_params_impl(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, bool zero_copy) {
     if (!cat || !params) return fail(MCD_ERR_INVALID, "null catalogue or params");
     if (n_walkers <= 0) return fail(MCD_ERR_INVALID, "n_walkers must be positive");
@@ -421,8 +437,9 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
         }
         shape.chunk_general = w.d_chunk_general;
         // records beyond what the caches hold between two passes: prefetch the next loop iteration's records (mcd_math.h)
-        shape.prefetch = cat->prefetch >= 0 ? cat->prefetch != 0
-                                            : (size_t)sh.n * (size_t)mcd::record_bytes(cat->model, cat->free_centre, cat->precision) >= ((size_t)8 << 20);
+        shape.prefetch = wants_prefetch(cat, sh);
+    cat->last_prefetch = shape.prefetch && shape.fast != 0;
+        cat->last_prefetch = shape.prefetch && shape.fast != 0;
         shape.rerun_flag = coll ? nullptr : out_buf + n_out;
         w.launch_tag = coll ? 0.0 : (double)(++cat->launch_seq);
         shape.launch_tag = w.launch_tag;
@@ -690,8 +707,8 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     const bool coll = ctx->n_ranks > 1 || ctx->force_collective;
     mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, level, w.uniform_len, sh.n};
     shape.chunk_general = w.d_chunk_general;
-    shape.prefetch = cat->prefetch >= 0 ? cat->prefetch != 0
-                                        : (size_t)sh.n * (size_t)mcd::record_bytes(cat->model, cat->free_centre, cat->precision) >= ((size_t)8 << 20);
+    shape.prefetch = wants_prefetch(cat, sh);
+    cat->last_prefetch = shape.prefetch && shape.fast != 0;
     double* const out_buf = w.d_out;
     shape.rerun_flag = coll ? nullptr : out_buf + half;
     const int bgk = mcd::bg_kind(cat->model);
@@ -1307,6 +1324,8 @@ int mcd_stretch_info(const mcd_catalog* cat, int64_t* device_blocks, int64_t* ho
     if (last_discard_status) *last_discard_status = cat->chain_last_status;
     return MCD_OK;
 }
+
+int mcd_last_prefetch(const mcd_catalog* cat) { return cat ? cat->last_prefetch : -1; }
 
 int mcd_last_fast_level(const mcd_catalog* cat) {
     if (!cat || cat->cur_walkers <= 0 || cat->shards.empty()) return -1;

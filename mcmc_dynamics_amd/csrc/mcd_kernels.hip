@@ -97,7 +97,7 @@ __device__ const double kExpTabSqrt2Device[kExpTabSize] = {MCD_EXP_TABLE_SQRT2_V
 
 // ------------------------------------------------------------------------------------------------
 // main kernel (the per-chunk arithmetic lives in mcd_math.h: chunk_loglike)
-template <int MODEL, bool FREE, class T, class A, int FAST>
+template <int MODEL, bool FREE, class T, class A, int FAST, bool PF>
 __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ recs,
                                                           const Chunk* __restrict__ chunks,
                                                           const T* __restrict__ wpar,
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
                                                           int n_wtiles, int64_t n_walkers, int64_t n_chunks,
                                                           int uniform_len, int64_t n_records,
                                                           double* __restrict__ rerun_flag, double launch_tag,
-                                                          const uint8_t* __restrict__ chunk_general, int prefetch) {
+                                                          const uint8_t* __restrict__ chunk_general) {
     constexpr int ND = record_doubles(MODEL, FREE);
     // fast mixtures: the 2^(j/1024) table of exp_tab lives in LDS (8 KiB per workgroup), four entries copied per thread
     constexpr bool kUsesExpTab = FAST && bg_kind(MODEL) != BG_NONE && sizeof(T) == 8;
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(kBlock) void loglike_kernel(const T* __restrict__ r
         // a chunk that holds a star outside the narrow-range domain (certain member, extreme background, ...) takes the
         // general fast form; the flag is wave-uniform (one scalar byte load), so this is a scalar branch
         const bool general = chunk_general != nullptr && chunk_general[chunk_id] != 0;
-        if (general) result = chunk_loglike<MODEL, FREE, T, A, 1>(chunk_recs, ch.count, w, denormal, exptab_lds, prefetch != 0);
-        else result = chunk_loglike<MODEL, FREE, T, A, 2>(chunk_recs, ch.count, w, denormal, exptab_lds, prefetch != 0);
+        if (general) result = chunk_loglike<MODEL, FREE, T, A, 1, PF>(chunk_recs, ch.count, w, denormal, exptab_lds);
+        else result = chunk_loglike<MODEL, FREE, T, A, 2, PF>(chunk_recs, ch.count, w, denormal, exptab_lds);
     } else {
-        result = chunk_loglike<MODEL, FREE, T, A, FAST>(chunk_recs, ch.count, w, denormal, exptab_lds, prefetch != 0);
+        result = chunk_loglike<MODEL, FREE, T, A, FAST, PF>(chunk_recs, ch.count, w, denormal, exptab_lds);
     }
     // denormal regime of the reference's log-sum-exp met: tell the host to re-evaluate this batch with the plain kernels
     // One device: the flag word gets this launch's tag.  Several ranks / devices (rerun_flag == nullptr): the partial sum
@@ -292,9 +292,15 @@ hipError_t launch_one(hipStream_t s, const void* records, const Chunk* chunks, i
     const int64_t n_tasks = n_chunks * n_wtiles;
     const int64_t grid = main_grid(n_chunks, n_walkers);   // > 256 walkers: XCD-aware grouping, see loglike_kernel
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST>), dim3((unsigned)grid), dim3(kBlock), 0, s,
-                       (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,
-                       uniform_len, n_records, rerun_flag, launch_tag, chunk_general, prefetch);
+    // the prefetching instantiation exists for the fast formulations only (the plain kernels have no prefetch code)
+    if (FAST != 0 && prefetch)
+        hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST, FAST != 0>), dim3((unsigned)grid), dim3(kBlock), 0, s,
+                           (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,
+                           uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
+    else
+        hipLaunchKernelGGL((loglike_kernel<MODEL, FREE, T, A, FAST, false>), dim3((unsigned)grid), dim3(kBlock), 0, s,
+                           (const T*)records, chunks, (const T*)wpar, partials, n_tasks, n_wtiles, n_walkers, n_chunks,
+                           uniform_len, n_records, rerun_flag, launch_tag, chunk_general);
     return hipGetLastError();
 }
 

@@ -760,31 +760,32 @@ struct KdeLane {
 #ifndef MCD_PREFETCH_DISTANCE
 #define MCD_PREFETCH_DISTANCE 1          // loop iterations ahead
 #endif
-template <int BYTES>
+template <int BYTES, bool ON>
 struct RecordPrefetch {
     static constexpr int kLines = (BYTES + 63) / 64 > 8 ? 8 : (BYTES + 63) / 64;
     uint32_t t;
-    // `enabled` is wave-uniform (a launch parameter): catalogues that fit the caches gain nothing from the prefetch and
-    // pay ~5 % for its bookkeeping (C2: 17.0 vs 16.1 us per step), so the library switches it on from 8 MiB of records up
+    // ON is a template parameter of the kernel, not a launch parameter: even switched off at run time the lane index,
+    // the predicate and the asm of retire() cost the tight CONST loops 6 - 16 % (C5: 190 us against 164 us compiled
+    // out).  Which launches get the prefetching instantiation: mcd_api.hip, wants_prefetch().
     template <class P>
-    MCD_HD void issue(P next, bool enabled) {
+    MCD_HD void issue(P next) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MCD_NO_PREFETCH)
-        const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        typedef const uint32_t __attribute__((address_space(1)))* global_word_ptr;
-        t = 0;
-        if (enabled && lane < (unsigned)kLines) t = *(global_word_ptr)((uint64_t)next + lane * 64u);
-#else
-        (void)next;
-        (void)enabled;
-        t = 0;
+        if constexpr (ON) {
+            const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            typedef const uint32_t __attribute__((address_space(1)))* global_word_ptr;
+            t = 0;
+            if (lane < (unsigned)kLines) t = *(global_word_ptr)((uint64_t)next + lane * 64u);
+            return;
+        }
 #endif
+        (void)next;
+        t = 0;
     }
     MCD_HD void retire(double anchor) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MCD_NO_PREFETCH)
-        asm volatile("" :: "v"(t), "v"(anchor));
-#else
-        (void)anchor;
+        if constexpr (ON) asm volatile("" :: "v"(t), "v"(anchor));
 #endif
+        (void)anchor;
     }
 };
 
@@ -851,9 +852,9 @@ MCD_HD constexpr bool exp_table_is_sqrt2_scaled(int model) { return model == MOD
 // FAST: 0 = plain (the reference's expressions term by term), 1 = fast formulation, 2 = fast formulation with the
 // narrow-range products of BgFixedAcc::add (MODEL_BGFIXED, MODEL_PROFILE_BGDENS) / BgGaussAcc::add (MODEL_BGGAUSS,
 // MODEL_PROFILE_BGGAUSS); for the models without background the same as 1.
-template <int MODEL, bool FREE, class T, class A, int FAST>
+template <int MODEL, bool FREE, class T, class A, int FAST, bool PF = false>
 MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bool& denormal,
-                            const double* __restrict__ exptab, bool prefetch = false) {
+                            const double* __restrict__ exptab) {
     constexpr int ND = record_doubles(MODEL, FREE);
     denormal = false;
     constexpr int XB = geometry_doubles(MODEL, FREE);      // first background slot of a record
@@ -865,8 +866,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         auto run4 = [&](auto& acc, auto&& one, auto&& rescale) {
             const int n4 = count >> 2;
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
-                RecordPrefetch<4 * ND * 4> pf;
-                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                RecordPrefetch<4 * ND * 4, PF> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) one(r + j * ND);
                 rescale();
@@ -913,8 +914,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         constexpr bool TREE16 = MODEL == MODEL_CONST && !FREE;
         const int n16 = TREE16 ? count >> 4 : 0;
         for (int g = 0; g < n16; ++g, r += 16 * ND) {
-            RecordPrefetch<16 * ND * 4> pf;
-            pf.issue(r + MCD_PREFETCH_DISTANCE * 16 * ND, prefetch);
+            RecordPrefetch<16 * ND * 4, PF> pf;
+            pf.issue(r + MCD_PREFETCH_DISTANCE * 16 * ND);
             float qq[16], nn[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -953,8 +954,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         constexpr bool TREE16 = MODEL == MODEL_CONST && !FREE;
         const int n16 = TREE16 ? count >> 4 : 0;
         for (int g = 0; g < n16; ++g, r += 16 * ND) {
-            RecordPrefetch<16 * ND * 8> pf;
-            pf.issue(r + MCD_PREFETCH_DISTANCE * 16 * ND, prefetch);
+            RecordPrefetch<16 * ND * 8, PF> pf;
+            pf.issue(r + MCD_PREFETCH_DISTANCE * 16 * ND);
             double qq[16], nn[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -967,8 +968,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         }
         const int n8 = TREE16 ? (count >> 3) & 1 : count >> 3;
         for (int g = 0; g < n8; ++g, r += 8 * ND) {
-            RecordPrefetch<8 * ND * 8> pf;
-            pf.issue(r + MCD_PREFETCH_DISTANCE * 8 * ND, prefetch);
+            RecordPrefetch<8 * ND * 8, PF> pf;
+            pf.issue(r + MCD_PREFETCH_DISTANCE * 8 * ND);
             double qq[8], nn[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1020,8 +1021,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         if constexpr (NARROW) {
             // eight raw factors per rescale: every second 4-star group (one scalar record-load batch each)
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
-                RecordPrefetch<4 * ND * 8> pf;
-                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                RecordPrefetch<4 * ND * 8, PF> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND);
                 four(r);
                 pf.retire(acc.l.p);
                 if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_narrow(); }    // wave-uniform: a scalar branch, not a select
@@ -1029,8 +1030,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
             if (n4 & 1) acc.rescale_narrow();
         } else {
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
-                RecordPrefetch<4 * ND * 8> pf;
-                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                RecordPrefetch<4 * ND * 8, PF> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND);
                 four(r);
                 pf.retire(acc.l.p);
                 acc.rescale();
@@ -1061,8 +1062,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         const int n4 = count >> 2;
         if constexpr (NARROW) {
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
-                RecordPrefetch<4 * ND * 8> pf;
-                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                RecordPrefetch<4 * ND * 8, PF> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND);
                 four(r);
                 pf.retire(acc.l.p);
                 if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_density_narrow(); }    // wave-uniform: a scalar branch, not a select
@@ -1070,8 +1071,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
             if (n4 & 1) acc.rescale_density_narrow();
         } else {
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
-                RecordPrefetch<4 * ND * 8> pf;
-                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                RecordPrefetch<4 * ND * 8, PF> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND);
                 four(r);
                 pf.retire(acc.l.p);
                 acc.rescale_density();
@@ -1107,8 +1108,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         const int n4 = count >> 2;
         if constexpr (NARROW) {
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
-                RecordPrefetch<4 * ND * 8> pf;
-                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                RecordPrefetch<4 * ND * 8, PF> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND);
                 four(r);
                 pf.retire(acc.ly.p);
                 if (g & 1) { MCD_KEEP_BRANCH(); acc.rescale_narrow(); }    // wave-uniform: a scalar branch, not a select
@@ -1116,8 +1117,8 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
             if (n4 & 1) acc.rescale_narrow();
         } else {
             for (int g = 0; g < n4; ++g, r += 4 * ND) {
-                RecordPrefetch<4 * ND * 8> pf;
-                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND, prefetch);
+                RecordPrefetch<4 * ND * 8, PF> pf;
+                pf.issue(r + MCD_PREFETCH_DISTANCE * 4 * ND);
                 four(r);
                 pf.retire(acc.ly.p);
                 acc.rescale();

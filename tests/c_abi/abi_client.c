@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
         (any_fn)mcd_last_error, (any_fn)mcd_abi_version, (any_fn)mcd_last_kernel_ms,
         (any_fn)mcd_last_device_ms, (any_fn)mcd_set_option, (any_fn)mcd_timing_collect,
         (any_fn)mcd_rerun_count, (any_fn)mcd_last_fast_level, (any_fn)mcd_last_launch_info,
-        (any_fn)mcd_ctx_comm_info, (any_fn)mcd_stretch_move, (any_fn)mcd_stretch_info};
+        (any_fn)mcd_ctx_comm_info, (any_fn)mcd_stretch_move, (any_fn)mcd_stretch_info, (any_fn)mcd_last_prefetch};
     size_t i;
     double out[3] = {0.0, 0.0, 0.0};
     for (i = 0; i < sizeof table / sizeof table[0]; ++i) CHECK(table[i] != NULL);
@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
     CHECK(mcd_catalog_create(NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_kde_background(NULL, 1, out, 1, out, out, 0.0, out, NULL) != MCD_OK);
     CHECK(mcd_last_fast_level(NULL) == -1);
+    CHECK(mcd_last_prefetch(NULL) == -1);
     CHECK(mcd_ctx_comm_info(NULL, NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_stretch_move(NULL, NULL, 1, out, out, NULL, out, out, NULL, NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_stretch_info(NULL, NULL, NULL, NULL, NULL) != MCD_OK);

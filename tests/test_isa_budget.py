@@ -11,13 +11,18 @@ import pytest
 from conftest import ROOT
 
 BUDGET = {                                   # VALU instructions per star-walker term, tools/isa_mix.py
-    "CONST fixed centre": 8.7,
-    "CONST free centre": 29.5,
-    "BGFIXED fixed centre": 34.3,
-    "BGFIXED fixed, narrow": 24.1,
-    "BGGAUSS fixed centre": 54.1,
-    "BGGAUSS fixed, narrow": 46.1,
-    "PROFILE fixed centre": 25.5,
+    "CONST fixed centre": 8.55,
+    "CONST free centre": 29.1,
+    "BGFIXED fixed centre": 33.8,
+    "BGFIXED fixed, narrow": 23.6,
+    "BGGAUSS fixed centre": 53.6,
+    "BGGAUSS fixed, narrow": 45.1,
+    "PROFILE fixed centre": 25.1,
+    # the instantiations that prefetch the next iteration's records (mcd_math.h: RecordPrefetch): + 2 instructions per
+    # iteration (lane index and predicate are hoisted, the touch and its exec mask are not)
+    "CONST fixed centre, prefetch": 8.7,
+    "BGFIXED fixed, narrow, prefetch": 24.1,
+    "BGGAUSS fixed, narrow, prefetch": 46.1,
 }
 
 
@@ -44,7 +49,8 @@ def test_hot_kernels_use_scalar_record_loads_and_no_scratch():
     if not os.path.exists(asm_path):
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py")], capture_output=True, timeout=900, check=True)
     asm = open(asm_path).read()
-    for tag, vgpr_limit in (("ILi0ELb0EddLi1E", 64), ("ILi1ELb0EddLi2E", 64), ("ILi2ELb0EddLi2E", 128)):
+    for tag, vgpr_limit in (("ILi0ELb0EddLi1ELb0E", 64), ("ILi1ELb0EddLi2ELb0E", 64), ("ILi1ELb0EddLi2ELb1E", 64),
+                            ("ILi2ELb0EddLi2ELb1E", 128)):
         m = re.search(r"\n(_ZN3mcd12_GLOBAL__N_114loglike_kernel" + tag + r"[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end", asm, re.S)
         assert m, tag
         body = m.group(2)

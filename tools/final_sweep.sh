@@ -1,6 +1,6 @@
 #!/bin/bash
 # Measurement sweep on the GPU box (repo root): GPU tests, smoke, every bench workload, rocprofv3 kernel statistics of
-# C3 and C2, the two PMC passes for roofline.traffic and the three SQ-counter passes.  Everything lands under
+# C3, C2 and a resident stretch-move block (tools/chain_probe.py), the two PMC passes for roofline.traffic and the three SQ-counter passes.  Everything lands under
 # gpurun_out/; tools/collect_profiles.sh then copies the summaries into profiles/ (see profiles/README.md).
 #     /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/final_sweep.sh TAG'
 set -o pipefail
@@ -25,6 +25,10 @@ echo "benches done"
 rm -rf $O/prof_${TAG}_c3 $O/prof_${TAG}_c2 $O/pmc_fetch_$TAG $O/pmc_write_$TAG
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c3 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/prof_bench_${TAG}_c3.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c2 -- python3 bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c2.log 2>&1 || exit 1
+rm -rf $O/prof_${TAG}_chain
+timeout -k 10 200 python tools/chain_probe.py > $O/chain_probe_$TAG.txt 2>&1 || { tail -5 $O/chain_probe_$TAG.txt; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_chain -- python3 tools/chain_probe.py 1000000 256 64 > $O/prof_chain_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 > $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 echo "kernel traces done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/pmc_fetch_$TAG.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/pmc_write_$TAG.log 2>&1 || exit 1

@@ -58,6 +58,8 @@ def source_hash():
     for name in SOURCES:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
+    with open(os.path.abspath(__file__), "rb") as f:       # the extraction rules are part of what the numbers mean
+        h.update(f.read())
     return h.hexdigest()[:16]
 
 
@@ -68,7 +70,12 @@ def analyse(out="/tmp/isa_mix"):
                    check=True, capture_output=True)
     asm = open(os.path.join(out, "mcd_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
     rows = []
-    for tag, name, key, per, trips, selector in KERNELS:
+    # every fast kernel exists with and without the software prefetch of the next iteration's records (template
+    # parameter PF, the last one of the mangled name): the main row is the instantiation without, `*_prefetch` fields and
+    # a second table line give the one with
+    variants = [(tag + "Lb0EE", name, key, per, trips, selector, False) for tag, name, key, per, trips, selector in KERNELS]
+    variants += [(tag + "Lb1EE", name + ", prefetch", key, per, trips, selector, True) for tag, name, key, per, trips, selector in KERNELS]
+    for tag, name, key, per, trips, selector, with_prefetch in variants:
         starts = [i for i, l in enumerate(asm) if l.startswith("_ZN3mcd12_GLOBAL__N_114loglike_kernel" + tag)]
         if not starts:
             continue
@@ -115,7 +122,7 @@ def analyse(out="/tmp/isa_mix"):
         slots = sum(v * (2.9 if o.startswith(("v_rsq_f64", "v_rcp_f64")) else
                          1.0 if (is_f64(o) and not o.startswith(("v_ldexp", "v_frexp"))) else 0.5)
                     for o, v in total.items() if o.startswith("v_"))
-        rows.append({"name": name, "model": key, "stars_per_iteration": terms,
+        rows.append({"name": name, "model": key, "prefetch": with_prefetch, "stars_per_iteration": terms,
                      "valu_per_term": valu / terms, "f64_per_term": f64 / terms, "trans_f64_per_term": trans / terms,
                      "other_per_term": (valu - f64) / terms, "slots_per_term": slots / terms,
                      "lds_per_term": sum(v for o, v in total.items() if o.startswith("ds_")) / terms,
@@ -123,20 +130,32 @@ def analyse(out="/tmp/isa_mix"):
     return rows
 
 
+def merge_variants(rows):
+    """{model: row of the instantiation without prefetch + `<field>_prefetch` for the one with}"""
+    out = {r["model"]: dict(r) for r in rows if not r["prefetch"]}
+    for r in rows:
+        if r["prefetch"] and r["model"] in out:
+            for k in ("valu_per_term", "f64_per_term", "other_per_term", "slots_per_term", "salu_smem_per_term"):
+                out[r["model"]][k + "_prefetch"] = r[k]
+    for r in out.values():
+        del r["prefetch"]
+    return out
+
+
 def main():
     rows = analyse()
-    print("{0:26s} {1:>9s} {2:>8s} {3:>8s} {4:>10s} {5:>14s}".format("kernel (fast path)", "VALU/term", "f64", "other",
+    print("{0:34s} {1:>9s} {2:>8s} {3:>8s} {4:>10s} {5:>14s}".format("kernel (fast path)", "VALU/term", "f64", "other",
                                                                     "slots/term", "predicted us"))
     for r in rows:
         pred = r["slots_per_term"] * SLOT_NS * (2.56e8 / 64) / 1024 * 1e-3
-        print("{0:26s} {1:9.2f} {2:8.2f} {3:8.2f} {4:10.2f} {5:14.1f}".format(r["name"], r["valu_per_term"], r["f64_per_term"],
+        print("{0:34s} {1:9.2f} {2:8.2f} {3:8.2f} {4:10.2f} {5:14.1f}".format(r["name"], r["valu_per_term"], r["f64_per_term"],
                                                                            r["other_per_term"], r["slots_per_term"], pred))
     if len(sys.argv) == 3 and sys.argv[1] == "--json":
         with open(sys.argv[2], "w") as f:
             json.dump({"source_sha16": source_hash(), "generated_by": "tools/isa_mix.py",
                        "note": "VALU wave-instructions per star-walker term in the hot loop nest of mcd::loglike_kernel "
                                "(gfx950 ISA from hipcc -save-temps); prologue, final log and tails not included",
-                       "kernels": {r["model"]: r for r in rows}}, f, indent=1, sort_keys=True)
+                       "kernels": merge_variants(rows)}, f, indent=1, sort_keys=True)
             f.write("\n")
 
 

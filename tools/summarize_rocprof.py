@@ -54,16 +54,25 @@ def pmc(workload, fetch_dir, write_dir, out, kernel_sub, compulsory=None):
         "fetch_bytes_raw": med(fetch) * 1024 if fetch else None,
         "fetch_bytes_x2_gfx950_wide_read_correction": med(fetch) * 2048 if fetch else None,
         "write_bytes": med(write) * 1024 if write else None,
-        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KB units (x1024). The x2 gfx950 "
-                "correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-B requests at 64 B) is calibrated for "
-                "16 B/lane vector streams; the record reads of this kernel are 64-B scalar loads (s_load_dwordx16). "
-                "Calibration on the known byte count of this access pattern: the kernel must read the whole record "
-                "array once (compulsory_bytes) and raw FETCH_SIZE equals it to 0.5 %, so the factor is 1.0 here.",
     }
-    entry["traffic_bytes_per_launch"] = (entry["fetch_bytes_raw"] or 0) + (entry["write_bytes"] or 0)
+    # gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE tallies a 128-byte request as 64 bytes, so streams that reach
+    # HBM as 128-byte requests (vector loads) read x2 of the counter, while 64-byte requests (the s_load_dwordx16 record
+    # reads of this kernel) read x1.  Which of the two a launch consists of is calibrated on a byte count that is known:
+    # the kernel must read the whole record array exactly once (compulsory_bytes).
+    factor = 2.0
     if compulsory:
         entry["compulsory_bytes"] = float(compulsory)
         entry["fetch_raw_over_compulsory"] = entry["fetch_bytes_raw"] / float(compulsory)
+        factor = 1.0 if entry["fetch_raw_over_compulsory"] > 0.75 else 2.0
+    entry["fetch_correction_factor"] = factor
+    entry["fetch_bytes"] = (entry["fetch_bytes_raw"] or 0) * factor
+    entry["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KB units (x1024).  Correction factor "
+                     "of FETCH_SIZE (see the comment in tools/summarize_rocprof.py): 2 when the records arrive through the "
+                     "vector path (the software prefetch of mcd_math.h: RecordPrefetch touches every line first, 128-byte "
+                     "requests; the scalar loads then hit in L2), 1 when they are fetched by the 64-byte scalar loads "
+                     "themselves (option prefetch = 0, and every profile before the prefetch existed); chosen by which of "
+                     "the two reproduces the compulsory read of the record array.")
+    entry["traffic_bytes_per_launch"] = entry["fetch_bytes"] + (entry["write_bytes"] or 0)
     data = {}
     if os.path.exists(out):
         data = json.load(open(out))
