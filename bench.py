@@ -568,8 +568,8 @@ def main():
         fit.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)     # pattern of bin/run_tests.py:92-93
         fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
         sampler = fit._make_sampler(n_walkers)             # emcee if importable, built-in stretch move otherwise
-        state = sampler.run_mcmc(pos, 80)                  # warm: a 64- and a 16-step block (work buffers, chain storage)
-        n_mcmc = 256                                       # four blocks of the built-in sampler (64 steps each)
+        state = sampler.run_mcmc(pos, 300)                 # warm: a full block and a short one (work buffers, chain storage)
+        n_mcmc = 1024                                      # four blocks of the built-in sampler (256 steps each)
         start = tuple(state)[0]
 
         def timed_chain():

@@ -32,6 +32,10 @@ class EnsembleSampler(object):
         self.a = float(a)
         self.vectorize = bool(vectorize)
         self.block_fn = block_fn
+        # steps whose random numbers are drawn together (and, with block_fn, run as one library call: the device then
+        # idles only once per block while the results travel back and the next block goes up, ~0.1 ms).  Part of the
+        # definition of the random stream: samplers that should produce the same chain need the same value.
+        self.block_steps = 256
         self._random = np.random.RandomState(seed)
         self.reset()
 
@@ -133,23 +137,24 @@ class EnsembleSampler(object):
                         np.ascontiguousarray(pick_b, dtype=np.int32))
             return order_b, zz_b, thr_b, pick_b
 
-        # With the loop inside the library the draws of the NEXT block (~2 ms for 64 steps of 256 walkers: a seventh of the
+        # With the loop inside the library the draws of the NEXT block (~2 ms per 64 steps of 256 walkers: a seventh of the
         # block's device time) are made by a helper thread while the library call of the current block waits for the
         # device -- both release the interpreter lock.  One generator, one drawing thread at a time, blocks drawn in order:
         # the stream of random numbers is the serial one.  (If the library call raises, the generator has already moved
         # past the block that was never run.)
         pool = None
-        if self.block_fn is not None and nsteps > 64:
+        chunk = max(1, int(self.block_steps))
+        if self.block_fn is not None and nsteps > chunk:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(max_workers=1)
         pending = None
         try:
             while done < nsteps:
-                block = min(64, nsteps - done)
+                block = min(chunk, nsteps - done)
                 order_b, zz_b, thr_b, pick_b = pending.result() if pending is not None else draw(block)
                 pending = None
                 if pool is not None and done + block < nsteps:
-                    pending = pool.submit(draw, min(64, nsteps - done - block))
+                    pending = pool.submit(draw, min(chunk, nsteps - done - block))
                 if self.block_fn is not None:
                     # the same half-step loop, in the library (csrc/mcd_stretch.h): identical numbers, no Python between launches
                     it = self.iteration

@@ -162,8 +162,10 @@ def test_library_stretch_move_equals_the_python_loop(case):
     pos[:, names.index("sigma_max")] = np.abs(pos[:, names.index("sigma_max")] * (1.0 + 0.5 * np.random.default_rng(1).normal(size=32)))
     native = fit._make_sampler(32, seed=11)
     assert isinstance(native, EnsembleSampler) and native.block_fn is not None
+    native.block_steps = 64
     native.run_mcmc(pos, 70)                                # a 64-step block and a 6-step block
     python = EnsembleSampler(32, len(names), fit.lnprob_batch, vectorize=True, seed=11)
+    python.block_steps = 64
     python.run_mcmc(pos, 70)
     assert np.array_equal(native.chain, python.chain) and np.array_equal(native.lnprobability, python.lnprobability)
     assert np.array_equal(native.acceptance_fraction, python.acceptance_fraction) and native.n_calls == python.n_calls

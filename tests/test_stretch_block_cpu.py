@@ -72,9 +72,11 @@ def test_library_stretch_block_equals_the_python_loop(case):
     start[:, 2] = np.clip(start[:, 2], -0.7, 0.8)
     start[:, 1] = np.minimum(start[:, 1], 1.4)
     ref = EnsembleSampler(24, P, lnprob, vectorize=True, seed=77)
+    ref.block_steps = 64                                   # several blocks (and the look-ahead drawing thread) in 150 steps
     ref.run_mcmc(start, 150)
     calls = []
     nat = EnsembleSampler(24, P, lnprob, vectorize=True, seed=77, block_fn=_block_fn(src, const, fac, lo, hi, True, calls))
+    nat.block_steps = 64
     pos, lnp, _ = nat.run_mcmc(start, 150)
     assert np.array_equal(nat.chain, ref.chain) and np.array_equal(nat.lnprobability, ref.lnprobability)
     assert np.array_equal(nat.acceptance_fraction, ref.acceptance_fraction) and nat.n_calls == ref.n_calls
