@@ -46,7 +46,8 @@ typedef enum {
     MCD_ERR_HIP = -2,       /* a HIP runtime call failed (message has the call)     */
     MCD_ERR_RCCL = -3,      /* an RCCL call failed                                  */
     MCD_ERR_NO_DEVICE = -4, /* no usable gfx950 device                              */
-    MCD_ERR_NONFINITE = -5  /* a NaN log-likelihood inside mcd_stretch_move         */
+    MCD_ERR_NONFINITE = -5, /* a NaN log-likelihood inside mcd_stretch_move         */
+    MCD_ERR_NOMEM = -6      /* host memory exhausted inside the library             */
 } mcd_status;
 
 /* which per-star likelihood the catalogue is evaluated with */

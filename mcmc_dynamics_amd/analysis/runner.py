@@ -361,17 +361,30 @@ class Runner(object):
             i += 1
         return initials
 
+    # Which sampler drives ``__call__``: "auto" (default) -- the built-in stretch move whenever whole blocks of steps can
+    # run inside the library (box priors: ``mcd_stretch_move``, ensemble resident on the device; 86 % of the kernel rate
+    # against ~60 % through per-call Python), otherwise emcee if it can be imported, otherwise the built-in one driving
+    # ``lnprob_batch``; "emcee": the real ``emcee.EnsembleSampler`` as the reference uses it (runner.py:403; ImportError
+    # when missing); "builtin": never emcee.  Both samplers make emcee's default move and expose emcee 3's attributes.
+    SAMPLER = "auto"
+
     def _make_sampler(self, n_walkers, seed=None):
-        try:
-            import emcee
-            sampler = emcee.EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True)
-            if seed is not None:
-                sampler._random.seed(seed)
-            return sampler
-        except ImportError:
-            from ..sampler import EnsembleSampler
-            return EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True, seed=seed,
-                                   block_fn=self._stretch_block if self._plan().simple and self.NATIVE_STRETCH else None)
+        if self.SAMPLER not in ("auto", "emcee", "builtin"):
+            raise ValueError("Runner.SAMPLER must be 'auto', 'emcee' or 'builtin'")
+        resident = self._plan().simple and self.NATIVE_STRETCH
+        if self.SAMPLER == "emcee" or (self.SAMPLER == "auto" and not resident):
+            try:
+                import emcee
+                sampler = emcee.EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True)
+                if seed is not None:
+                    sampler._random.seed(seed)
+                return sampler
+            except ImportError:
+                if self.SAMPLER == "emcee":
+                    raise
+        from ..sampler import EnsembleSampler
+        return EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True, seed=seed,
+                               block_fn=self._stretch_block if resident else None)
 
     NATIVE_STRETCH = True          # sub-classes whose posterior is not ONE un-binned catalogue switch this off
 

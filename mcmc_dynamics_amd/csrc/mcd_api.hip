@@ -32,8 +32,25 @@ namespace {
 thread_local std::string g_last_error;
 
 int fail(int code, const std::string& msg) {
-    g_last_error = msg;
+    try { g_last_error = msg; } catch (...) { g_last_error.clear(); }       // (assigning can allocate)
     return code;
+}
+
+// Every entry point that can allocate host memory (std::vector / std::map / std::string) runs inside try / catch and
+// lands here: no C++ exception crosses the C boundary, the caller gets a status code and a message instead.
+int on_exception(const char* where) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        try { g_last_error = std::string(where) + ": out of host memory"; } catch (...) { g_last_error.clear(); }
+        return MCD_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        try { g_last_error = std::string(where) + ": internal error: " + e.what(); } catch (...) { g_last_error.clear(); }
+        return MCD_ERR_INVALID;
+    } catch (...) {
+        g_last_error.clear();
+        return MCD_ERR_INVALID;
+    }
 }
 
 #define MCD_HIP(call)                                                                                   \
@@ -826,6 +843,7 @@ const char* mcd_last_error(void) { return g_last_error.c_str(); }
 int mcd_abi_version(void) { return MCD_ABI_VERSION; }
 
 int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out) {
+    try {
     if (!out || n_dev <= 0) return fail(MCD_ERR_INVALID, "mcd_ctx_create: bad arguments");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(MCD_ERR_NO_DEVICE, "no HIP device visible");
@@ -862,9 +880,11 @@ int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out) {
     ctx->multi_process = false;
     *out = ctx.release();
     return MCD_OK;
+    } catch (...) { return on_exception("mcd_ctx_create"); }
 }
 
 int mcd_get_unique_id(void* out_id) {
+    try {
     if (!out_id) return fail(MCD_ERR_INVALID, "null id buffer");
     static_assert(sizeof(ncclUniqueId) <= MCD_UNIQUE_ID_BYTES, "unique id does not fit");
     int rc = load_rccl();
@@ -874,9 +894,11 @@ int mcd_get_unique_id(void* out_id) {
     std::memset(out_id, 0, MCD_UNIQUE_ID_BYTES);
     std::memcpy(out_id, &id, sizeof id);
     return MCD_OK;
+    } catch (...) { return on_exception("mcd_get_unique_id"); }
 }
 
 int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id, mcd_ctx** out) {
+    try {
     if (!out || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(MCD_ERR_INVALID, "mcd_ctx_create_rank: bad arguments");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(MCD_ERR_NO_DEVICE, "no HIP device visible");
@@ -901,6 +923,7 @@ int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id
     ctx->multi_process = true;
     *out = ctx.release();
     return MCD_OK;
+    } catch (...) { return on_exception("mcd_ctx_create_rank"); }
 }
 
 int mcd_ctx_destroy(mcd_ctx* ctx) {
@@ -918,6 +941,7 @@ int mcd_ctx_destroy(mcd_ctx* ctx) {
 int mcd_ctx_n_devices(const mcd_ctx* ctx) { return ctx ? (int)ctx->slots.size() : 0; }
 
 int mcd_ctx_comm_info(const mcd_ctx* ctx, int* comm_size, int* comm_rank, int* rccl_version) {
+    try {
     if (!ctx || ctx->slots.empty()) return fail(MCD_ERR_INVALID, "mcd_ctx_comm_info: null context");
     if (comm_size) *comm_size = 0;
     if (comm_rank) *comm_rank = -1;
@@ -932,11 +956,13 @@ int mcd_ctx_comm_info(const mcd_ctx* ctx, int* comm_size, int* comm_rank, int* r
     if (comm_rank) *comm_rank = r;
     if (rccl_version) *rccl_version = v;
     return MCD_OK;
+    } catch (...) { return on_exception("mcd_ctx_comm_info"); }
 }
 
 static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::unique_ptr<mcd_catalog>& cat);
 
 int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** out) {
+    try {
     if (!ctx || !d || !out) return fail(MCD_ERR_INVALID, "mcd_catalog_create: null argument");
     std::unique_ptr<mcd_catalog> cat;
     const int rc = catalog_create_impl(ctx, d, cat);
@@ -950,6 +976,7 @@ int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** ou
     }
     *out = cat.release();
     return MCD_OK;
+    } catch (...) { return on_exception("mcd_catalog_create"); }
 }
 
 static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::unique_ptr<mcd_catalog>& cat) {
@@ -1068,14 +1095,21 @@ int64_t mcd_catalog_n_outputs(const mcd_catalog* cat, int64_t n_walkers) {
 }
 
 int mcd_params_upload(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params) {
-    return stage_params(cat, n_walkers, k, params, false);
+    try { return stage_params(cat, n_walkers, k, params, false); } catch (...) { return on_exception("mcd_params_upload"); }
 }
 
-int mcd_loglike_enqueue(mcd_catalog* cat) { return enqueue(cat, true); }
-int mcd_loglike_fetch(mcd_catalog* cat, double* out) { return fetch(cat, out); }
-int mcd_sync(mcd_catalog* cat) { return sync_all(cat); }
+int mcd_loglike_enqueue(mcd_catalog* cat) {
+    try { return enqueue(cat, true); } catch (...) { return on_exception("mcd_loglike_enqueue"); }
+}
+int mcd_loglike_fetch(mcd_catalog* cat, double* out) {
+    try { return fetch(cat, out); } catch (...) { return on_exception("mcd_loglike_fetch"); }
+}
+int mcd_sync(mcd_catalog* cat) {
+    try { return sync_all(cat); } catch (...) { return on_exception("mcd_sync"); }
+}
 
 int mcd_loglike_batch(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, double* out) {
+    try {
     if (!out) return fail(MCD_ERR_INVALID, "null output");
     const bool collective = cat && (cat->ctx->n_ranks > 1 || cat->ctx->slots.size() > 1 || cat->ctx->force_collective);
     int rc = stage_params(cat, n_walkers, k, params, !collective && cat && cat->zero_copy);
@@ -1083,6 +1117,7 @@ int mcd_loglike_batch(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
     rc = enqueue(cat, false);
     if (rc != MCD_OK) return rc;
     return fetch(cat, out);
+    } catch (...) { return on_exception("mcd_loglike_batch"); }
 }
 
 namespace {
@@ -1113,11 +1148,15 @@ int per_star(mcd_catalog* cat, int32_t k, const double* params, int mode, double
 }  // namespace
 
 int mcd_membership(mcd_catalog* cat, int32_t k, const double* params, double* out) {
+    try {
     return per_star(cat, k, params, 0, out);
+    } catch (...) { return on_exception("mcd_membership"); }
 }
 
 int mcd_loglike_per_star(mcd_catalog* cat, int32_t k, const double* params, double* out) {
+    try {
     return per_star(cat, k, params, 1, out);
+    } catch (...) { return on_exception("mcd_loglike_per_star"); }
 }
 
 namespace {
@@ -1136,6 +1175,7 @@ struct KdeScratch {
 
 int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t n, const double* v,
                        const double* verr, double sigma_int, double* out, double* kernel_ms) {
+    try {
     if (kernel_ms) *kernel_ms = 0.0;
     if (!ctx || ctx->slots.empty()) return fail(MCD_ERR_INVALID, "kde background: null context");
     if (n < 0 || n_comp < 0) return fail(MCD_ERR_INVALID, "kde background: negative size");
@@ -1171,11 +1211,13 @@ int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t
         *kernel_ms = ms;
     }
     return MCD_OK;
+    } catch (...) { return on_exception("mcd_kde_background"); }
 }
 
 int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
                      const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
                      double* lnprob_chain, int64_t* accepted) {
+    try {
     if (!cat || !d || !pos || !lnp || !order || !zz || !thr || !pick) return fail(MCD_ERR_INVALID, "mcd_stretch_move: null argument");
     if (cat->n_psets != 1) return fail(MCD_ERR_INVALID, "mcd_stretch_move: un-binned catalogues only");
     if (d->k != cat->k) return fail(MCD_ERR_INVALID, "mcd_stretch_move: descriptor has the wrong number of kernel columns");
@@ -1207,9 +1249,11 @@ int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_step
     if (rc == mcd::STRETCH_NAN) return fail(MCD_ERR_NONFINITE, "mcd_stretch_move: the log-likelihood returned NaN");
     if (rc != mcd::STRETCH_OK) return fail(MCD_ERR_INVALID, "mcd_stretch_move: bad arguments");
     return MCD_OK;
+    } catch (...) { return on_exception("mcd_stretch_move"); }
 }
 
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
+    try {
     if (!cat || !key) return fail(MCD_ERR_INVALID, "mcd_set_option: null argument");
     if (!std::strcmp(key, "timing")) {
         int rc = sync_all(cat);
@@ -1293,9 +1337,11 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     return fail(MCD_ERR_INVALID, std::string("unknown option: ") + key);
+    } catch (...) { return on_exception("mcd_set_option"); }
 }
 
 int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_launches) {
+    try {
     if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
     int rc = sync_all(cat);
     if (rc != MCD_OK) return rc;
@@ -1311,6 +1357,7 @@ int mcd_timing_collect(mcd_catalog* cat, double* total_kernel_ms, int64_t* n_lau
     for (Shard& s2 : cat->shards) s2.ring_used = 0;
     cat->timing_launches = 0;                  // the first launch after a collect is sampled
     return MCD_OK;
+    } catch (...) { return on_exception("mcd_timing_collect"); }
 }
 
 int64_t mcd_rerun_count(const mcd_catalog* cat) { return cat ? cat->n_reruns : MCD_ERR_INVALID; }

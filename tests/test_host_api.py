@@ -421,3 +421,42 @@ def test_lnprob_batch_direct_route_equals_the_general_one(monkeypatch):
         assert fit._plan().direct_cols is None
         fit._catalog_key = fit._plan().catalog_key
         assert fit.lnprob_batch(pos[:, 1:]).shape == (64,)
+
+
+def test_sampler_selection(monkeypatch):
+    """Runner.SAMPLER: box priors take the built-in stretch move with the library's block entry (whatever is importable),
+    expression priors take emcee when it is there, and "emcee" / "builtin" force either (runner.py:403 is what "emcee"
+    reproduces)."""
+    import sys
+    import types
+    g = load_golden("constant_fixed")
+    cf = ConstantFit(DataReader({k: g[k] for k in ("ra", "dec", "v", "verr")}))
+    cf.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+    cf.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+    made = []
+
+    class FakeEnsembleSampler(object):
+        def __init__(self, nwalkers, ndim, fn, vectorize=False):
+            made.append((nwalkers, ndim, vectorize))
+            self._random = np.random.RandomState()
+
+    monkeypatch.setitem(sys.modules, "emcee", types.SimpleNamespace(EnsembleSampler=FakeEnsembleSampler))
+    s = cf._make_sampler(16, seed=3)
+    assert isinstance(s, EnsembleSampler) and s.block_fn is not None and not made          # resident blocks beat emcee
+    cf.SAMPLER = "emcee"
+    assert isinstance(cf._make_sampler(16, seed=3), FakeEnsembleSampler) and made == [(16, 4, True)]
+    cf.SAMPLER = "builtin"
+    assert isinstance(cf._make_sampler(16), EnsembleSampler) and len(made) == 1
+    cf.SAMPLER = "auto"
+    cf.parameters["sigma_max"].set(lnprior="-0.5 * (sigma_max - 10.0)**2")                  # not a box prior any more
+    assert not cf._plan().simple
+    assert isinstance(cf._make_sampler(16), FakeEnsembleSampler) and len(made) == 2
+    monkeypatch.setitem(sys.modules, "emcee", None)                                          # import emcee -> ImportError
+    s = cf._make_sampler(16)
+    assert isinstance(s, EnsembleSampler) and s.block_fn is None
+    cf.SAMPLER = "emcee"
+    with pytest.raises(ImportError):
+        cf._make_sampler(16)
+    cf.SAMPLER = "nonsense"
+    with pytest.raises(ValueError):
+        cf._make_sampler(16)
