@@ -57,16 +57,19 @@ inline ChunkPlan plan_chunks(const std::vector<int64_t>& bin_offsets, int64_t st
     ChunkPlan plan;
     const int64_t n_psets = (int64_t)bin_offsets.size() - 1;
     const int64_t n_wtiles = (n_walkers + 63) / 64;
-    // >= 256 walkers: `target_waves` full-length waves (default 10240 = 1.25 full-occupancy sets of 256 CUs x 4 SIMDs x 8
-    // waves), i.e. ~1.5 rounds of resident waves once the guided tail is added.  <= 192 walkers (a workgroup's four waves
-    // are spread over several chunks): ONE round -- ~6600 waves plus the ~25 % extra chunks of the guided tail; 1.1 - 1.5
-    // rounds, where the last round runs nearly empty, cost 10 - 25 % (tools/chunk_len_probe.py).  The default was 12288
-    // until the records were prefetched (mcd_math.h: RecordPrefetch): with the memory latency hidden, the longer chunks
-    // of 10240 (1e6 stars: 416 instead of 352 per chunk at 256 walkers, 352 instead of 288 at 128) win 1.5 - 3 % by
-    // writing and reducing fewer partial sums (tools/w128_sweep.py, tools/ab_option.sh).
+    // 256 walkers: `target_waves` full-length waves (default 10240 = 1.25 full-occupancy sets of 256 CUs x 4 SIMDs x 8
+    // waves), i.e. ~1.5 rounds of resident waves once the guided tail is added; more than 256 walkers (several workgroups
+    // per chunk): 1.2 x that (C5, 55 bins x 512 walkers: 158.6 us per step against 162.6).  <= 192 walkers (a workgroup's
+    // four waves are spread over several chunks): ONE round -- 0.6 target_waves - 136 = 6008 waves plus the ~25 % extra
+    // chunks of the guided tail; 1.1 - 1.5 rounds, where the last round runs nearly empty, cost 10 - 25 %
+    // (tools/chunk_len_probe.py, tools/w128_len_sweep.py: 1e6 stars x 128 walkers 105.7 us per step at 416 stars per
+    // chunk, 107.7 at 352, 110.2 at 288, 119.9 at 480; x 64 walkers 64.1 at 224, 66.6 at 160).  The default was 12288
+    // until the records were prefetched (mcd_math.h: RecordPrefetch): with the memory latency hidden, longer chunks win
+    // 1.5 - 3 % by writing and reducing fewer partial sums (tools/w128_sweep.py, tools/ab_option.sh).
     int64_t len;
-    if (n_wtiles >= 4) len = (n * n_wtiles + target_waves - 1) / std::max<int64_t>(1, target_waves);
-    else len = (5 * n * n_wtiles / 4 + (target_waves * 2 / 3 - 192) - 1) / std::max<int64_t>(1, target_waves * 2 / 3 - 192);
+    if (n_wtiles > 4) len = (5 * n * n_wtiles + 6 * target_waves - 1) / std::max<int64_t>(1, 6 * target_waves);
+    else if (n_wtiles == 4) len = (n * n_wtiles + target_waves - 1) / std::max<int64_t>(1, target_waves);
+    else len = (5 * n * n_wtiles / 4 + (target_waves * 3 / 5 - 136) - 1) / std::max<int64_t>(1, target_waves * 3 / 5 - 136);
     if (chunk_len > 0) {
         len = std::max<int64_t>(64, (chunk_len + 31) / 32 * 32);   // explicit nominal length (option "chunk_len", tuning)
     } else {

@@ -74,9 +74,11 @@ def test_guided_schedule_ends_on_short_chunks_and_equal_schedule_is_arithmetic()
     # chunk length is capped so that per-chunk exponent sums stay inside int32
     huge = em.plan_chunks([0, 8 << 20], 0, 8 << 20, 64, 1, 0)
     assert huge["len"] == (1 << 20) - 32 and huge["count"].max() == (1 << 20) - 32
-    # fewer, longer chunks for <= 128 walkers; never a multiple of 64 stars
-    assert em.plan_chunks([0, 1000000], 0, 1000000, 128, 12288, 1)["len"] == 288
+    # fewer, longer chunks for <= 128 walkers (one round of waves); never a multiple of 64 stars; the library's default
+    # target (10240): 416 stars per chunk at 256 and 128 walkers, 224 at 64, shorter chunks again beyond 256 walkers
+    assert em.plan_chunks([0, 1000000], 0, 1000000, 128, 12288, 1)["len"] == 352
     assert em.plan_chunks([0, 1000000], 0, 1000000, 64, 12288, 1)["len"] == 160
+    assert [em.plan_chunks([0, 1000000], 0, 1000000, w, 10240, 1)["len"] for w in (64, 128, 256, 512)] == [224, 416, 416, 672]
     assert em.plan_chunks([0, 1250000], 0, 1250000, 256, 12288, 1)["len"] == 416
     assert em.plan_chunks([0, 5000], 0, 5000, 256, 12288, 1)["len"] == 96
 
