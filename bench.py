@@ -593,6 +593,34 @@ def main():
             mcmc["host_driven_steps_per_s"] = n_mcmc / dt_host
         fit.close()
 
+    if world == 1 and n_bins > 1 and not args.no_mcmc and model == "const" and args.precision == "f64":
+        # C5: one ensemble per radial bin in lockstep (the reference runs one MCMC per bin, bin/run_tests.py:75-124);
+        # blocks of steps inside the library (mcd_stretch_move with n_bins = B) and, beside it, the NumPy loop
+        import logging
+        from mcmc_dynamics_amd import DataReader
+        from mcmc_dynamics_amd.analysis import BinnedConstantFit
+        from mcmc_dynamics_amd.analysis.binned import BinnedSampler
+        logging.getLogger("mcmc_dynamics_amd").setLevel(logging.ERROR)
+        reader = DataReader({k: cat[k] for k in ("ra", "dec", "v", "verr")})
+        reader.make_radial_bins(synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG, nstars=1000, dlogr=0.05)
+        fit = BinnedConstantFit(reader, context=ctx)
+        fit.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)
+        fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
+        rates = {}
+        for label, block_fn, n_mcmc in (("library", fit._stretch_block, 128), ("numpy_loop", None, 8)):
+            sampler = BinnedSampler(fit.n_bins, n_walkers, fit.n_fitted_parameters, fit.lnprob_batch, seed=5, block_fn=block_fn)
+            state = sampler.run_mcmc(pos, 4 if block_fn is None else 70)
+            t2 = time.perf_counter()
+            sampler.run_mcmc(state[0], n_mcmc, log_prob0=state[1])
+            rates[label] = n_mcmc / (time.perf_counter() - t2)
+            acc = float(np.mean(sampler.acceptance_fraction))
+        mcmc = {"steps_per_s": rates["library"], "terms_per_s": float(len(cat["v"])) * n_walkers * rates["library"],
+                "driver": "mcmc_dynamics_amd.analysis.binned.BinnedSampler", "posterior": "BinnedConstantFit.lnprob_batch",
+                "ensembles": fit.n_bins, "calls_per_step": 2, "walkers_per_call": n_walkers // 2, "steps": 128,
+                "acceptance_fraction": acc, "numpy_loop_steps_per_s": rates["numpy_loop"],
+                "stretch_blocks": fit._catalog.stretch_info()}
+        fit.close()
+
     # per-rank figures of the headline workload, gathered before the catalogue goes away
     kernel_us_ranks = [kernel_s * 1e6]
     if group is not None:

@@ -184,8 +184,14 @@ int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t
  *   pick  [n_steps][2][W/2]  partner index into the complementary half
  * pos [W][n_dim] and lnp [W] are updated in place; chain [n_steps][W][n_dim], lnprob_chain [n_steps][W] (either may be
  * NULL) receive the state after every step; accepted [W] (may be NULL) is incremented.  The chain is bit-identical to the
- * one the Python loop produces from the same numbers.  Un-binned catalogues only.  Returns MCD_ERR_NONFINITE when the
- * likelihood produced a NaN (emcee raises "Probability function returned NaN").
+ * one the Python loop produces from the same numbers.  Returns MCD_ERR_NONFINITE when the likelihood produced a NaN (emcee
+ * raises "Probability function returned NaN").
+ *
+ * Binned catalogues (desc->n_bins = B = the catalogue's number of radial bins): B independent ensembles, one per bin --
+ * the reference runs one MCMC per bin (bin/run_tests.py:75-124) -- advance in lockstep and share every evaluation (one
+ * launch of B x W/2 rows per half step).  Every array gains a bin dimension in front of the walker dimension:
+ * pos [B][W][n_dim], lnp [B][W], accepted [B][W], order [n_steps][B][W], zz / thr / pick [n_steps][2][B][W/2],
+ * chain [n_steps][B][W][n_dim], lnprob_chain [n_steps][B][W]; prior bounds and column map are shared by the bins.
  *
  * Where it runs.  A float64 catalogue on one device per process (single GPU, or one rank of a multi-process job) keeps
  * the ensemble RESIDENT on the device for the block: positions, log-probabilities and the block's random numbers are
@@ -206,7 +212,8 @@ typedef struct {
     const double* lo;           /* [n_dim] inclusive prior bounds; -inf / +inf where unbounded */
     const double* hi;
     int32_t fixed_ok;           /* 0: a fixed parameter violates its own bounds, every proposal is rejected (runner.py:207-214) */
-    int32_t reserved;
+    int32_t n_bins;             /* 0 or 1: one ensemble (un-binned catalogue); B > 1: B lock-stepped ensembles, one per
+                                 * parameter set (radial bin) of the catalogue -- must equal its number of bins */
 } mcd_stretch_desc;
 
 int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* desc, int64_t n_steps, double* pos, double* lnp,

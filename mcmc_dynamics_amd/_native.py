@@ -88,7 +88,7 @@ class StretchDesc(ctypes.Structure):
     _fields_ = [
         ("n_walkers", ctypes.c_int64), ("n_dim", ctypes.c_int32), ("k", ctypes.c_int32),
         ("col_source", ctypes.POINTER(ctypes.c_int32)), ("col_const", _c_double_p), ("col_factor", _c_double_p),
-        ("lo", _c_double_p), ("hi", _c_double_p), ("fixed_ok", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("lo", _c_double_p), ("hi", _c_double_p), ("fixed_ok", ctypes.c_int32), ("n_bins", ctypes.c_int32),
     ]
 
 
@@ -342,29 +342,38 @@ class Catalog(object):
         """``mcd_stretch_move``: advance the ensemble by ``len(order)`` stretch-move steps with the half-step loop inside
         the library.  ``plan``: dict with ``col_source`` (int32 [K]), ``col_const``, ``col_factor`` (float64 [K]), ``lo``,
         ``hi`` (float64 [P]) and ``fixed_ok``.  ``pos`` (W, P) and ``lnp`` (W,) are C-contiguous float64 arrays updated
-        in place; random numbers as drawn by ``sampler.EnsembleSampler``."""
+        in place; random numbers as drawn by ``sampler.EnsembleSampler``.
+
+        Binned catalogues: ``pos`` (B, W, P), ``lnp`` (B, W), ``order`` (steps, B, W), ``zz`` / ``thr`` / ``pick``
+        (steps, 2, B, W/2), ``chain`` (steps, B, W, P), ``lnprob_chain`` (steps, B, W), ``accepted`` (B, W): B independent
+        ensembles in lockstep, one per radial bin, as ``analysis.binned.BinnedSampler`` draws them."""
         self._alive()
-        n_steps, w = order.shape
-        p = pos.shape[1]
+        binned = pos.ndim == 3
+        lead = pos.shape[:1] if binned else ()
+        n_bins = pos.shape[0] if binned else 1
+        n_steps, w = order.shape[0], order.shape[-1]
+        p = pos.shape[-1]
         for a, dt in ((pos, np.float64), (lnp, np.float64), (zz, np.float64), (thr, np.float64), (order, np.int32), (pick, np.int32)):
             if a.dtype != dt or not a.flags.c_contiguous:
                 raise ValueError("stretch_move needs C-contiguous arrays of the documented dtypes")
-        if pos.shape != (w, p) or lnp.shape != (w,) or zz.shape != (n_steps, 2, w // 2) or thr.shape != zz.shape or pick.shape != zz.shape:
+        half_shape = (n_steps, 2) + lead + (w // 2,)
+        if pos.shape != lead + (w, p) or lnp.shape != lead + (w,) or order.shape != (n_steps,) + lead + (w,) or \
+                zz.shape != half_shape or thr.shape != half_shape or pick.shape != half_shape:
             raise ValueError("stretch_move: inconsistent array shapes")
         cols = [np.ascontiguousarray(plan["col_source"], dtype=np.int32), _f64(plan["col_const"]), _f64(plan["col_factor"]),
                 _f64(plan["lo"]), _f64(plan["hi"])]
         if cols[0].size != self.k or cols[1].size != self.k or cols[2].size != self.k or cols[3].size != p or cols[4].size != p:
             raise ValueError("stretch_move: plan does not match the catalogue / the number of free parameters")
         d = StretchDesc()
-        d.n_walkers, d.n_dim, d.k = w, p, self.k
+        d.n_walkers, d.n_dim, d.k, d.n_bins = w, p, self.k, n_bins
         d.col_source = cols[0].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
         d.col_const, d.col_factor, d.lo, d.hi = (_ptr(c) for c in cols[1:])
         d.fixed_ok = 1 if plan.get("fixed_ok", True) else 0
-        for a, shape in ((chain, (n_steps, w, p)), (lnprob_chain, (n_steps, w))):
+        for a, shape in ((chain, (n_steps,) + lead + (w, p)), (lnprob_chain, (n_steps,) + lead + (w,))):
             if a is not None and (a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape):
-                raise ValueError("stretch_move: chain buffers must be C-contiguous float64 of shape (steps, W, P) / (steps, W)")
-        if accepted is not None and (accepted.dtype != np.int64 or accepted.shape != (w,) or not accepted.flags.c_contiguous):
-            raise ValueError("stretch_move: accepted must be a C-contiguous int64 array of length W")
+                raise ValueError("stretch_move: chain buffers must be C-contiguous float64 of shape (steps, [B,] W, P) / (steps, [B,] W)")
+        if accepted is not None and (accepted.dtype != np.int64 or accepted.shape != lead + (w,) or not accepted.flags.c_contiguous):
+            raise ValueError("stretch_move: accepted must be a C-contiguous int64 array of shape ([B,] W)")
         rc = self.lib.mcd_stretch_move(self.handle, ctypes.byref(d), n_steps, _ptr(pos), _ptr(lnp),
                                        order.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(zz), _ptr(thr),
                                        pick.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(chain), _ptr(lnprob_chain),

@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcd.h"
@@ -622,17 +623,39 @@ int fetch(mcd_catalog* cat, double* out) {
 // mcd_stretch_move with the ensemble resident on the device (mcd_stretch.hip).  Runs the whole block as one chain of
 // launches and waits once.  *done = false (and nothing of the caller's touched) when the block has to be run host-driven:
 // the configuration is not covered, or the device met something only the host loop handles (mcd::ChainStatus).
+// user <-> pinned copies of tens of MB (a binned block: 40 MB of random numbers in, 70 MB of chain rows out) on four
+// threads: one core moves ~10 GB/s, the copies would otherwise cost as much as the block's device time
+void big_copy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kSerial = (size_t)4 << 20;
+    if (bytes < kSerial) { std::memcpy(dst, src, bytes); return; }
+    constexpr int kThreads = 4;
+    std::thread workers[kThreads - 1];
+    const size_t part = (bytes / kThreads + 63) / 64 * 64;
+    for (int t = 1; t < kThreads; ++t) {
+        const size_t at = std::min(bytes, part * t), len = std::min(bytes, part * (t + 1)) - at;
+        workers[t - 1] = std::thread([=] { if (len) std::memcpy((char*)dst + at, (const char*)src + at, len); });
+    }
+    std::memcpy(dst, src, std::min(bytes, part));
+    for (auto& th : workers) th.join();
+}
+
 int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
                          const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
                          double* lnprob_chain, int64_t* accepted, bool* done) {
     *done = false;
     mcd_ctx* ctx = cat->ctx;
-    if (!cat->device_chain || cat->shards.size() != 1 || cat->precision != MCD_F64 || cat->n_psets != 1 || n_steps < 1 ||
-        cat->timing || !d->fixed_ok)
+    const int64_t B = cat->n_psets;                    // ensembles: one per parameter set (mcd_stretch_move checked n_bins)
+    if (!cat->device_chain || cat->shards.size() != 1 || cat->precision != MCD_F64 || n_steps < 1 || cat->timing || !d->fixed_ok)
         return MCD_OK;
+    if (B > 1 && cat->device_chain != 1) return MCD_OK;            // (the testing variants exist for one ensemble only)
     if (cat->chain_backoff > 0) { --cat->chain_backoff; return MCD_OK; }
     const int64_t W = d->n_walkers, half = W / 2;
     const int P = d->n_dim, K = d->k;
+    {
+        mcd::StretchDevice probe;
+        probe.n_bins = B; probe.n_walkers = W; probe.n_dim = P; probe.k = K;
+        if (!mcd::stretch_step_handles(probe)) return MCD_OK;
+    }
     Shard& sh = cat->shards[0];
     const DeviceSlot& slot = ctx->slots[sh.slot];
     MCD_HIP(hipSetDevice(slot.device));
@@ -647,19 +670,21 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     w.staged = false;                     // the walker constants are about to be overwritten on the device
 
     // ---- arena layout: [state, copied both ways | inputs, copied in | scratch | chain rows, copied out] ----
+    // (every per-walker array carries the ensemble index in front: [B][W]..., random numbers [n_steps][..][B][..])
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 63) / 64 * 64; return at; };
-    const size_t o_pos = take((size_t)W * P * 8), o_lnp = take((size_t)W * 8), o_acc = take((size_t)W * 8);
+    const size_t BW = (size_t)B * W, Bh = (size_t)B * half;
+    const size_t o_pos = take(BW * P * 8), o_lnp = take(BW * 8), o_acc = take(BW * 8);
     const size_t o_meta = take(mcd::META_WORDS * 4), o_status = take(8);
     const size_t state_end = off;
     const size_t o_src = take((size_t)K * 4), o_const = take((size_t)K * 8), o_fac = take((size_t)K * 8);
     const size_t o_lo = take((size_t)P * 8), o_hi = take((size_t)P * 8);
-    const size_t o_order = take((size_t)n_steps * W * 4), o_zz = take((size_t)n_steps * W * 8);
-    const size_t o_thr = take((size_t)n_steps * W * 8), o_pick = take((size_t)n_steps * W * 4);
+    const size_t o_order = take((size_t)n_steps * BW * 4), o_zz = take((size_t)n_steps * BW * 8);
+    const size_t o_thr = take((size_t)n_steps * BW * 8), o_pick = take((size_t)n_steps * BW * 4);
     const size_t input_end = off;
-    const size_t o_prop = take((size_t)half * P * 8), o_ok = take((size_t)half);
-    const size_t o_chain = take(chain ? (size_t)n_steps * W * P * 8 : 0);
-    const size_t o_lnpc = take(lnprob_chain ? (size_t)n_steps * W * 8 : 0);
+    const size_t o_prop = take(Bh * P * 8), o_ok = take(Bh), o_nok = take((size_t)2 * B * 4), o_ranges = take((size_t)2 * B * 10 * 8);
+    const size_t o_chain = take(chain ? (size_t)n_steps * BW * P * 8 : 0);
+    const size_t o_lnpc = take(lnprob_chain ? (size_t)n_steps * BW * 8 : 0);
     const size_t total = off;
     ChainArena& a = cat->chain;
     if (a.bytes < total) {
@@ -675,10 +700,10 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         }
         a.bytes = want;
     }
-    std::memcpy(a.h + o_pos, pos, (size_t)W * P * 8);
-    std::memcpy(a.h + o_lnp, lnp, (size_t)W * 8);
-    if (accepted) std::memcpy(a.h + o_acc, accepted, (size_t)W * 8);
-    else std::memset(a.h + o_acc, 0, (size_t)W * 8);
+    std::memcpy(a.h + o_pos, pos, BW * P * 8);
+    std::memcpy(a.h + o_lnp, lnp, BW * 8);
+    if (accepted) std::memcpy(a.h + o_acc, accepted, BW * 8);
+    else std::memset(a.h + o_acc, 0, BW * 8);
     std::memset(a.h + o_meta, 0, mcd::META_WORDS * 4);
     std::memset(a.h + o_status, 0, 8);
     std::memcpy(a.h + o_src, d->col_source, (size_t)K * 4);
@@ -686,25 +711,26 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     std::memcpy(a.h + o_fac, d->col_factor, (size_t)K * 8);
     std::memcpy(a.h + o_lo, d->lo, (size_t)P * 8);
     std::memcpy(a.h + o_hi, d->hi, (size_t)P * 8);
-    std::memcpy(a.h + o_order, order, (size_t)n_steps * W * 4);
-    std::memcpy(a.h + o_zz, zz, (size_t)n_steps * W * 8);
-    std::memcpy(a.h + o_thr, thr, (size_t)n_steps * W * 8);
-    std::memcpy(a.h + o_pick, pick, (size_t)n_steps * W * 4);
+    big_copy(a.h + o_order, order, (size_t)n_steps * BW * 4);
+    big_copy(a.h + o_zz, zz, (size_t)n_steps * BW * 8);
+    big_copy(a.h + o_thr, thr, (size_t)n_steps * BW * 8);
+    big_copy(a.h + o_pick, pick, (size_t)n_steps * BW * 4);
 
     // kernel family of this block: what the device's guard last asked for, else the verdict on the current positions
     int level = cat->chain_hint;
     if (level < 0) {
-        std::vector<double> table((size_t)W * K);
-        for (int64_t j = 0; j < W; ++j)
+        std::vector<double> table(BW * K);
+        for (size_t j = 0; j < BW; ++j)
             for (int c = 0; c < K; ++c) {
                 const int src = d->col_source[c];
                 table[j * K + c] = src < 0 ? d->col_const[c]
                                            : (d->col_factor[c] == 1.0 ? pos[j * P + src] : pos[j * P + src] * d->col_factor[c]);
             }
-        level = fast_level(cat, table.data(), W);
+        level = fast_level(cat, table.data(), (int64_t)BW);
     }
 
     mcd::StretchDevice sd;
+    sd.n_bins = B;
     sd.n_walkers = W; sd.n_dim = P; sd.k = K; sd.fixed_ok = d->fixed_ok;
     sd.model = cat->model; sd.free_centre = cat->free_centre ? 1 : 0; sd.allow_fast = cat->allow_fast;
     sd.expected_level = level;
@@ -718,6 +744,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     sd.chain = chain ? (double*)(a.d + o_chain) : nullptr;
     sd.lnprob_chain = lnprob_chain ? (double*)(a.d + o_lnpc) : nullptr;
     sd.proposal = (double*)(a.d + o_prop); sd.ok = (uint8_t*)(a.d + o_ok); sd.meta = (int32_t*)(a.d + o_meta);
+    sd.n_ok = (int32_t*)(a.d + o_nok); sd.ranges = (double*)(a.d + o_ranges);
     sd.table = w.d_params; sd.wpar = (double*)w.d_wpar;
 
     MCD_HIP(hipMemcpyAsync(a.d, a.h, input_end, hipMemcpyHostToDevice, slot.stream));
@@ -727,7 +754,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     shape.prefetch = wants_prefetch(cat, sh);
     cat->last_prefetch = shape.prefetch && shape.fast != 0;
     double* const out_buf = w.d_out;
-    shape.rerun_flag = coll ? nullptr : out_buf + half;
+    shape.rerun_flag = coll ? nullptr : out_buf + Bh;
     const int bgk = mcd::bg_kind(cat->model);
     const double* pset_const = (level && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
     double prev_tag = 0.0;
@@ -748,11 +775,11 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
             prev_tag = coll ? 0.0 : (double)(++cat->launch_seq);
             shape.launch_tag = prev_tag;
             MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, half));
-            MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, 1, w.n_chunks, w.max_chunks_per_pset, half,
+            MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, B, w.n_chunks, w.max_chunks_per_pset, half,
                                        pset_const, out_buf));
             if (coll) {
                 if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
-                MCD_NCCL(g_rccl.AllReduce(out_buf, out_buf, (size_t)half, ncclDouble, ncclSum, slot.comm, slot.stream));
+                MCD_NCCL(g_rccl.AllReduce(out_buf, out_buf, Bh, ncclDouble, ncclSum, slot.comm, slot.stream));
                 if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
             }
             acc_step = i;
@@ -809,11 +836,11 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     cat->chain_consecutive = 0;
     cat->chain_hint = level;
     ++cat->chain_device_blocks;
-    std::memcpy(pos, a.h + o_pos, (size_t)W * P * 8);
-    std::memcpy(lnp, a.h + o_lnp, (size_t)W * 8);
-    if (accepted) std::memcpy(accepted, a.h + o_acc, (size_t)W * 8);
-    if (chain) std::memcpy(chain, a.h + o_chain, (size_t)n_steps * W * P * 8);
-    if (lnprob_chain) std::memcpy(lnprob_chain, a.h + o_lnpc, (size_t)n_steps * W * 8);
+    std::memcpy(pos, a.h + o_pos, BW * P * 8);
+    std::memcpy(lnp, a.h + o_lnp, BW * 8);
+    if (accepted) std::memcpy(accepted, a.h + o_acc, BW * 8);
+    if (chain) big_copy(chain, a.h + o_chain, (size_t)n_steps * BW * P * 8);
+    if (lnprob_chain) big_copy(lnprob_chain, a.h + o_lnpc, (size_t)n_steps * BW * 8);
     *done = true;
     return MCD_OK;
 }
@@ -1219,7 +1246,9 @@ int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_step
                      double* lnprob_chain, int64_t* accepted) {
     try {
     if (!cat || !d || !pos || !lnp || !order || !zz || !thr || !pick) return fail(MCD_ERR_INVALID, "mcd_stretch_move: null argument");
-    if (cat->n_psets != 1) return fail(MCD_ERR_INVALID, "mcd_stretch_move: un-binned catalogues only");
+    const int64_t B = d->n_bins > 1 ? d->n_bins : 1;
+    if (B != cat->n_psets)
+        return fail(MCD_ERR_INVALID, "mcd_stretch_move: desc->n_bins must equal the catalogue's number of parameter sets (radial bins)");
     if (d->k != cat->k) return fail(MCD_ERR_INVALID, "mcd_stretch_move: descriptor has the wrong number of kernel columns");
     if (d->n_walkers <= 0 || (d->n_walkers & 1) || d->n_dim <= 0 || n_steps < 0)
         return fail(MCD_ERR_INVALID, "mcd_stretch_move: n_walkers must be positive and even, n_dim positive");
@@ -1227,11 +1256,12 @@ int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_step
     for (int c = 0; c < d->k; ++c)
         if (d->col_source[c] >= d->n_dim) return fail(MCD_ERR_INVALID, "mcd_stretch_move: col_source outside the free parameters");
     const int64_t W = d->n_walkers, half = W / 2;
-    for (int64_t i = 0; i < n_steps * W; ++i)
+    for (int64_t i = 0; i < n_steps * B * W; ++i)
         if (order[i] < 0 || order[i] >= W) return fail(MCD_ERR_INVALID, "mcd_stretch_move: order holds an index outside 0..W-1");
-    for (int64_t i = 0; i < n_steps * W; ++i)
+    for (int64_t i = 0; i < n_steps * B * W; ++i)
         if (pick[i] < 0 || pick[i] >= half) return fail(MCD_ERR_INVALID, "mcd_stretch_move: pick holds an index outside the half ensemble");
     mcd::StretchDesc sd;
+    sd.n_bins = B;
     sd.n_walkers = W; sd.n_dim = d->n_dim; sd.k = d->k; sd.col_source = d->col_source; sd.col_const = d->col_const;
     sd.col_factor = d->col_factor; sd.lo = d->lo; sd.hi = d->hi; sd.fixed_ok = d->fixed_ok;
     bool done = false;

@@ -65,7 +65,8 @@ enum ChainStatus : int {
     CHAIN_NO_PROPOSAL = 8    // a half step without a single proposal inside the prior (the host loop skips the evaluation)
 };
 struct StretchDevice {
-    int64_t n_walkers = 0;                 // W (even)
+    int64_t n_bins = 1;                    // B ensembles (one per parameter set of the catalogue), one workgroup each
+    int64_t n_walkers = 0;                 // W (even), per ensemble
     int32_t n_dim = 0, k = 0;              // free parameters; columns of the kernel parameter table
     int32_t fixed_ok = 1;
     int32_t model = 0, free_centre = 0;
@@ -94,6 +95,8 @@ struct StretchDevice {
     double* proposal = nullptr;            // [W/2][P]
     uint8_t* ok = nullptr;                 // [W/2]   proposal inside the prior
     int32_t* meta = nullptr;               // [META_WORDS]
+    int32_t* n_ok = nullptr;               // [2][B] proposals inside the prior, per ensemble and half-step parity
+    double* ranges = nullptr;              // [2][B][10] ParamRanges of each ensemble's table (B > 1: judged by the next launch)
     double* table = nullptr;               // [W/2][k]   resolved parameter rows (the guard reads them back)
     double* wpar = nullptr;                // [W/2][KD]  derived walker constants: what the main kernel reads
 };
@@ -101,6 +104,8 @@ struct StretchDevice {
 hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t acc_step, int acc_h, int64_t prop_step,
                                int prop_h, const double* ll, double rerun_tag);
 hipError_t launch_stretch_status(hipStream_t s, const int32_t* meta, double* out);
+// several ensembles need the step kernel that keeps an ensemble in LDS (<= 512 walkers, <= 12 columns, <= 32 KiB of positions)
+bool stretch_step_handles(const StretchDevice& d);
 
 // background.SingleStars (mcd_kde.hip): slice plan and launch.  part_dmin / part_sum hold [n_slices][n] doubles.
 int kde_slices(int64_t n, int64_t m, int* slice_len);

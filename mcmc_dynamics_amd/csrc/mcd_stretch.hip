@@ -192,6 +192,16 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
                                                                          const double* __restrict__ ll, double rerun_tag) {
     const int half = (int)(d.n_walkers / 2), W = 2 * half, P = d.n_dim, K = d.k;
     const int j = threadIdx.x;
+    // one workgroup per ensemble (radial bin): arrays carry the bin index in front of the walker index
+    const int64_t B = d.n_bins, b = blockIdx.x;
+    double* const pos_b = d.pos + b * W * P;
+    double* const lnp_b = d.lnp + b * W;
+    double* const proposal_b = d.proposal + b * half * P;
+    uint8_t* const ok_b = d.ok + b * half;
+    const double* const ll_b = ll + b * half;
+    // n_ok and the guard's ranges are kept per half-step parity: workgroup 0 judges the PREVIOUS table of all ensembles
+    // while the other workgroups already write the next one's
+    const int64_t slot_acc = ((acc_step * 2 + acc_h) & 1) * B, slot_prop = ((prop_step * 2 + prop_h) & 1) * B;
     const bool active = j < half, do_acc = acc_step >= 0, do_prop = prop_step >= 0;
     __shared__ int s_wave_ok[kStepBlock / 64], s_wave_first[kStepBlock / 64];
     __shared__ double s_ranges[kStepBlock / 64][10];
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
     // round trip per iteration, 3.5 us for the four iterations of 256 walkers x 4 columns)
     {
         constexpr int kPairs = kSmallPosBytes / 16 / kStepBlock;          // double2 loads per thread that cover the largest ensemble
-        const double2* __restrict__ src = reinterpret_cast<const double2*>(d.pos);
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(pos_b);
         const int n_pairs = W * P / 2;                                     // (W is even)
         double2 r[kPairs];
 #pragma unroll
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
             const int x = j + u * kStepBlock;
             r[u] = x < n_pairs ? src[x] : make_double2(0.0, 0.0);
         }
-        const double l0 = j < W ? d.lnp[j] : 0.0, l1 = j + kStepBlock < W ? d.lnp[j + kStepBlock] : 0.0;
+        const double l0 = j < W ? lnp_b[j] : 0.0, l1 = j + kStepBlock < W ? lnp_b[j + kStepBlock] : 0.0;
 #pragma unroll
         for (int u = 0; u < kPairs; ++u) {
             const int x = j + u * kStepBlock;
@@ -231,24 +241,24 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
     double ll_j = 0.0, thr_j = 0.0, flag_word = 0.0;
     double prev[kMaxCols];
     if (do_acc) {
-        n_ok_prev = d.meta[META_N_OK];
-        if (j == 0 && rerun_tag != 0.0) flag_word = ll[half];
+        n_ok_prev = d.n_ok[slot_acc + b];
+        if (b == 0 && j == 0 && rerun_tag != 0.0) flag_word = ll[B * half];
         if (active) {
-            ok_prev = d.ok[j] != 0;
-            ll_j = ll[j];
-            w_acc = d.order[acc_step * W + (acc_h == 0 ? 0 : half) + j];
-            thr_j = d.thr[(acc_step * 2 + acc_h) * half + j];
+            ok_prev = ok_b[j] != 0;
+            ll_j = ll_b[j];
+            w_acc = d.order[(acc_step * B + b) * W + (acc_h == 0 ? 0 : half) + j];
+            thr_j = d.thr[((acc_step * 2 + acc_h) * B + b) * half + j];
 #pragma unroll
-            for (int c = 0; c < kMaxCols; ++c) prev[c] = c < P ? d.proposal[j * P + c] : 0.0;
+            for (int c = 0; c < kMaxCols; ++c) prev[c] = c < P ? proposal_b[j * P + c] : 0.0;
         }
     }
     int w_s = 0, pick_j = 0;
     double z_j = 0.0;
     if (do_prop && active) {
-        w_s = d.order[prop_step * W + (prop_h == 0 ? 0 : half) + j];
-        s_second[j] = d.order[prop_step * W + (prop_h == 0 ? half : 0) + j];
-        pick_j = d.pick[(prop_step * 2 + prop_h) * half + j];
-        z_j = d.zz[(prop_step * 2 + prop_h) * half + j];
+        w_s = d.order[(prop_step * B + b) * W + (prop_h == 0 ? 0 : half) + j];
+        s_second[j] = d.order[(prop_step * B + b) * W + (prop_h == 0 ? half : 0) + j];
+        pick_j = d.pick[((prop_step * 2 + prop_h) * B + b) * half + j];
+        z_j = d.zz[((prop_step * 2 + prop_h) * B + b) * half + j];
     }
     if (do_prop && j < kMaxCols) {
         s_lo[j] = j < P ? d.lo[j] : 0.0;
@@ -261,23 +271,48 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
     MCD_STAMP(1);
     // ---- accept / reject (walkers of one half step are distinct: no two threads touch the same row) ----
     if (do_acc) {
-        if (j == 0 && rerun_tag != 0.0 && flag_word == rerun_tag) atomicOr(&d.meta[META_STATUS], CHAIN_RERUN);
+        if (b == 0 && j == 0 && rerun_tag != 0.0 && flag_word == rerun_tag) atomicOr(&d.meta[META_STATUS], CHAIN_RERUN);
+        if (B > 1 && b == 0) {
+            // several ensembles: was the kernel family of the launch whose sums arrive now the one the guard picks for
+            // the table of all ensembles?  (each workgroup of the previous launch left its ensemble's ranges in memory;
+            // ensembles without a valid proposal raised CHAIN_NO_PROPOSAL themselves)
+            ParamRanges mine;
+            for (int64_t e = j; e < B; e += kStepBlock)
+                if (d.n_ok[slot_acc + e] > 0) mine.merge(load_ranges(d.ranges + (slot_acc + e) * 10));
+            wave_merge(mine);
+            if ((j & 63) == 0) store_ranges(mine, s_ranges[j >> 6]);
+            __syncthreads();
+            if (j == 0) {
+                ParamRanges all = load_ranges(s_ranges[0]);
+                for (int i = 1; i < kStepBlock / 64; ++i) all.merge(load_ranges(s_ranges[i]));
+                int level = 0;
+                if (d.allow_fast) {
+                    level = level_verdict(d.stats, d.model, false, B * half, all);
+                    if (d.allow_fast == 2 && level > 1) level = 1;
+                }
+                if (level != d.expected_level && !(d.meta[META_STATUS] & CHAIN_NO_PROPOSAL)) {
+                    if (!(d.meta[META_STATUS] & CHAIN_LEVEL)) d.meta[META_LEVEL] = level;
+                    atomicOr(&d.meta[META_STATUS], CHAIN_LEVEL);
+                }
+            }
+            __syncthreads();                           // (s_ranges is used again by the propose phase)
+        }
         if (active) {
             const double new_lnp = (n_ok_prev > 0 && ok_prev) ? ll_j : -kInfinity;
             if (new_lnp != new_lnp) atomicOr(&d.meta[META_STATUS], CHAIN_NAN);
             if (thr_j < new_lnp - s_lnp[w_acc]) {
 #pragma unroll
                 for (int c = 0; c < kMaxCols; ++c)
-                    if (c < P) { s_pos[w_acc * P + c] = prev[c]; d.pos[w_acc * P + c] = prev[c]; }
+                    if (c < P) { s_pos[w_acc * P + c] = prev[c]; pos_b[w_acc * P + c] = prev[c]; }
                 s_lnp[w_acc] = new_lnp;
-                d.lnp[w_acc] = new_lnp;
-                atomicAdd((unsigned long long*)&d.accepted[w_acc], 1ull);
+                lnp_b[w_acc] = new_lnp;
+                atomicAdd((unsigned long long*)&d.accepted[b * W + w_acc], 1ull);
             }
         }
         __syncthreads();                              // the ensemble is final for this half step
         if (acc_h == 1) {
-            if (d.chain) for (int x = j; x < W * P; x += kStepBlock) d.chain[acc_step * W * P + x] = s_pos[x];
-            if (d.lnprob_chain) for (int w = j; w < W; w += kStepBlock) d.lnprob_chain[acc_step * W + w] = s_lnp[w];
+            if (d.chain) for (int x = j; x < W * P; x += kStepBlock) d.chain[(acc_step * B + b) * W * P + x] = s_pos[x];
+            if (d.lnprob_chain) for (int w = j; w < W; w += kStepBlock) d.lnprob_chain[(acc_step * B + b) * W + w] = s_lnp[w];
         }
     }
     MCD_STAMP(2);
@@ -294,13 +329,13 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
                 const double sc = s_pos[w_s * P + c], qc = s_pos[w_q * P + c];
                 const double v = qc - (qc - sc) * z_j;
                 mine_prop[c] = v;
-                d.proposal[j * P + c] = v;
+                proposal_b[j * P + c] = v;
                 good = good && (v >= s_lo[c]) && (v <= s_hi[c]);
             } else {
                 mine_prop[c] = 0.0;
             }
         }
-        d.ok[j] = good;
+        ok_b[j] = good;
     }
     // how many proposals lie inside the prior, and the first of them: one ballot per wave (LDS atomics of 64 lanes on
     // one address are served lane by lane: 2.5 us for the two of them)
@@ -341,9 +376,9 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
 #pragma unroll
         for (int c = 0; c < kMaxCols; ++c) {
             row[c] = resolved[c];
-            if (c < K) d.table[j * K + c] = resolved[c];
+            if (c < K) d.table[(b * half + j) * K + c] = resolved[c];
         }
-        walker_constants<double>(row, d.model, d.free_centre != 0, d.wpar + j * KD);
+        walker_constants<double>(row, d.model, d.free_centre != 0, d.wpar + (b * half + j) * KD);
         mine.add_row(row, K, d.model, d.free_centre != 0);
     }
     MCD_STAMP(5);
@@ -352,20 +387,27 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
     __syncthreads();
     MCD_STAMP(6);
     if (j == 0) {
-        d.meta[META_N_OK] = n_ok;
+        d.n_ok[slot_prop + b] = n_ok;
         if (n_ok == 0) {
+            // (with several ensembles the host loop would lend this one a valid row of another: it takes the block back)
             atomicOr(&d.meta[META_STATUS], CHAIN_NO_PROPOSAL);
         } else {
             ParamRanges all = load_ranges(s_ranges[0]);
             for (int i = 1; i < kStepBlock / 64; ++i) all.merge(load_ranges(s_ranges[i]));
-            int level = 0;
-            if (d.allow_fast) {
-                level = level_verdict(d.stats, d.model, false, half, all);
-                if (d.allow_fast == 2 && level > 1) level = 1;
-            }
-            if (level != d.expected_level) {
-                if (!(d.meta[META_STATUS] & CHAIN_LEVEL)) d.meta[META_LEVEL] = level;
-                atomicOr(&d.meta[META_STATUS], CHAIN_LEVEL);
+            if (B > 1) {
+                // the guard's verdict is on the table of ALL ensembles: this one's ranges go to memory and workgroup 0 of
+                // the next launch judges them together (below, judge_all_ensembles)
+                store_ranges(all, d.ranges + (slot_prop + b) * 10);
+            } else {
+                int level = 0;
+                if (d.allow_fast) {
+                    level = level_verdict(d.stats, d.model, false, half, all);
+                    if (d.allow_fast == 2 && level > 1) level = 1;
+                }
+                if (level != d.expected_level) {
+                    if (!(d.meta[META_STATUS] & CHAIN_LEVEL)) d.meta[META_LEVEL] = level;
+                    atomicOr(&d.meta[META_STATUS], CHAIN_LEVEL);
+                }
             }
         }
     }
@@ -378,18 +420,29 @@ __global__ void stretch_status_kernel(const int32_t* meta, double* out) { out[0]
 
 }  // namespace
 
+namespace {
+bool small_step(const StretchDevice& d) {
+    const size_t pos_bytes = (size_t)d.n_walkers * d.n_dim * sizeof(double);
+    const int cols = d.k > d.n_dim ? d.k : d.n_dim;
+    return d.n_walkers <= 2 * kStepBlock && cols <= 12 && pos_bytes <= (size_t)kSmallPosBytes && !d.force_general;
+}
+}  // namespace
+
+bool stretch_step_handles(const StretchDevice& d) { return d.n_bins == 1 || small_step(d); }
+
 hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t acc_step, int acc_h, int64_t prop_step,
                                int prop_h, const double* ll, double rerun_tag) {
     const size_t pos_bytes = (size_t)d.n_walkers * d.n_dim * sizeof(double);
     const size_t lds = pos_bytes + (size_t)d.n_walkers * sizeof(double) + (size_t)(d.n_walkers / 2) * sizeof(int32_t);
     const int cols = d.k > d.n_dim ? d.k : d.n_dim;
-    const bool small = d.n_walkers <= 2 * kStepBlock && cols <= 12 && pos_bytes <= (size_t)kSmallPosBytes && !d.force_general;
+    const bool small = small_step(d);
+    if (!small && d.n_bins != 1) return hipErrorInvalidValue;
     if (small && cols <= 4)
-        hipLaunchKernelGGL(stretch_step_small_kernel<4>, dim3(1), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+        hipLaunchKernelGGL(stretch_step_small_kernel<4>, dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
     else if (small && cols <= 8)
-        hipLaunchKernelGGL(stretch_step_small_kernel<8>, dim3(1), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+        hipLaunchKernelGGL(stretch_step_small_kernel<8>, dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
     else if (small)
-        hipLaunchKernelGGL(stretch_step_small_kernel<12>, dim3(1), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+        hipLaunchKernelGGL(stretch_step_small_kernel<12>, dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
     else
         hipLaunchKernelGGL(stretch_step_kernel, dim3(1), dim3(kStepBlock), 0, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
     return hipGetLastError();

@@ -244,13 +244,13 @@ extern "C" int64_t emul_narrow_exceptions(int model, int64_t n, const double* v,
 // ---------------------------------------------------------------------------------------------------------------
 // The library's stretch-move block (csrc/mcd_stretch.h) with the likelihood supplied by the test as a callback.
 typedef int (*emul_eval_fn)(const double* table, int64_t n, double* out);
-extern "C" int emul_stretch_block(int64_t W, int P, int K, const int32_t* col_source, const double* col_const,
+extern "C" int emul_stretch_block(int64_t B, int64_t W, int P, int K, const int32_t* col_source, const double* col_const,
                                   const double* col_factor, const double* lo, const double* hi, int fixed_ok,
                                   int64_t n_steps, double* pos, double* lnp, const int32_t* order, const double* zz,
                                   const double* thr, const int32_t* pick, double* chain, double* lnprob_chain,
                                   int64_t* accepted, emul_eval_fn eval) {
     StretchDesc d;
-    d.n_walkers = W; d.n_dim = P; d.k = K; d.col_source = col_source; d.col_const = col_const; d.col_factor = col_factor;
+    d.n_bins = B; d.n_walkers = W; d.n_dim = P; d.k = K; d.col_source = col_source; d.col_const = col_const; d.col_factor = col_factor;
     d.lo = lo; d.hi = hi; d.fixed_ok = fixed_ok;
     return stretch_block(d, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted,
                          [&](const double* t, int64_t n, double* out) { return eval(t, n, out); });

@@ -48,7 +48,7 @@ class ShardCatalog(object):
         cols = [np.ascontiguousarray(plan["col_source"], dtype=np.int32)] + \
             [np.ascontiguousarray(plan[key], dtype=np.float64) for key in ("col_const", "col_factor", "lo", "hi")]
         ptr = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t)) if a is not None else None
-        rc = lib.emul_stretch_block(ctypes.c_int64(pos.shape[0]), pos.shape[1], k, ptr(cols[0], ctypes.c_int32),
+        rc = lib.emul_stretch_block(ctypes.c_int64(1), ctypes.c_int64(pos.shape[0]), pos.shape[1], k, ptr(cols[0], ctypes.c_int32),
                                     *[ptr(c, ctypes.c_double) for c in cols[1:]], int(plan.get("fixed_ok", True)),
                                     ctypes.c_int64(order.shape[0]), ptr(pos, ctypes.c_double), ptr(lnp, ctypes.c_double),
                                     ptr(order, ctypes.c_int32), ptr(zz, ctypes.c_double), ptr(thr, ctypes.c_double),

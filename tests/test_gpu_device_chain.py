@@ -292,3 +292,76 @@ def test_resident_chain_through_the_collective_path(native, kind):
     assert same(dev, run_block(plain, plan, pos, lnp, randoms, device=True))
     plain.close()
     cat.close()
+
+
+def test_binned_ensembles_resident_equal_host_driven(native):
+    """n_bins = B: one workgroup of the step kernel per ensemble (radial bin), one main-kernel launch of B x W/2 rows per
+    half step, the guard judged on the table of all ensembles by the next launch.  Resident against host-driven, bit for
+    bit; an ensemble without a single valid proposal makes the device give the block back."""
+    from mcmc_dynamics_amd import DataReader
+    from mcmc_dynamics_amd.analysis import BinnedConstantFit
+    g = load_golden("radial_bins")
+    reader = DataReader({k: g[k] for k in ("ra", "dec", "v", "verr")})
+    reader.make_radial_bins(float(g["ra_center"]), float(g["dec_center"]), nstars=200, dlogr=0.05)
+    bf = BinnedConstantFit(reader)
+    bf.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+    bf.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+    B, W, P = bf.n_bins, 40, 4
+    assert B > 3
+    rng = np.random.default_rng(9500)
+    pos = np.array([3.0, 9.0, 1.0, -1.0]) * (1.0 + 0.2 * rng.normal(size=(B, W, P)))
+    pos[..., 1] = np.abs(pos[..., 1]) + 0.5
+    pos = np.ascontiguousarray(pos)
+    lnp = np.ascontiguousarray(bf.lnprob_batch(pos))
+    assert np.all(np.isfinite(lnp))
+    cat = bf._catalog
+    plan = dict(bf._stretch_plan())
+    plan["lo"] = plan["lo"].copy()
+    plan["hi"] = plan["hi"].copy()
+    plan["hi"][0] = pos[..., 0].max() - 0.3                             # cuts into the ensembles: rows get rejected
+    half = W // 2
+
+    def numbers(n):
+        order = np.argsort(rng.random((n, B, W)), axis=2).astype(np.int32)
+        u = rng.random((n, 4, B, half))
+        zz = np.ascontiguousarray((u[:, :2] + 1.0) ** 2 / 2.0)
+        thr = np.ascontiguousarray(np.log(u[:, 2:]) - (P - 1.0) * np.log(zz))
+        return order, zz, thr, rng.integers(0, half, size=(n, 2, B, half)).astype(np.int32)
+
+    def run(mode, p0, l0, r):
+        cat.set_option("device_chain", mode)
+        n = r[0].shape[0]
+        p, l = p0.copy(), l0.copy()
+        chain, lnpc, acc = np.empty((n, B, W, P)), np.empty((n, B, W)), np.zeros((B, W), dtype=np.int64)
+        cat.stretch_move(plan, p, l, *r, chain, lnpc, acc)
+        return p, l, chain, lnpc, acc
+
+    ok0 = pos[..., 0] <= plan["hi"][0]
+    start, start_lnp = pos.copy(), lnp.copy()
+    start[~ok0] = start[ok0][0]                                          # every start position inside the prior
+    start_lnp = np.ascontiguousarray(bf.lnprob_batch(start))
+    r = numbers(15)
+    before = cat.stretch_info()
+    dev = run(1, start, start_lnp, r)
+    info = cat.stretch_info()
+    assert info["device_blocks"] == before["device_blocks"] + 1 and info["discarded_blocks"] == before["discarded_blocks"], info
+    host = run(0, start, start_lnp, r)
+    assert same(dev, host)
+    acc = dev[4]
+    assert acc.sum() > 0 and np.all(acc.sum(axis=1) > 0) and np.all(np.isfinite(dev[3]))
+    assert np.all(dev[2][..., 0] <= plan["hi"][0])
+    r2 = numbers(4)                                                      # a second block continues from the first
+    assert same(run(1, dev[0], dev[1], r2), run(0, host[0], host[1], r2))
+    # one ensemble entirely outside the prior: every proposal of that bin is rejected -> the device gives the block back
+    # (the host loop lends such a bin a valid row of another bin)
+    far = start.copy()
+    far[2, :, 0] = plan["hi"][0] + 50.0
+    far_lnp = start_lnp.copy()
+    far_lnp[2] = -np.inf
+    r3 = numbers(3)
+    before = cat.stretch_info()
+    dev3 = run(1, far, far_lnp, r3)
+    info = cat.stretch_info()
+    assert info["discarded_blocks"] == before["discarded_blocks"] + 1 and info["last_discard_status"] & 8, info
+    assert same(dev3, run(0, far, far_lnp, r3)) and np.array_equal(dev3[0][2], far[2])
+    bf.close()

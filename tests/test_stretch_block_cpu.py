@@ -32,7 +32,7 @@ def _block_fn(src, const, fac, lo, hi, fixed_ok, calls):
 
     def run(pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted):
         p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t)) if a is not None else None
-        rc = lib.emul_stretch_block(ctypes.c_int64(pos.shape[0]), pos.shape[1], k, p(src, ctypes.c_int32), p(const, ctypes.c_double),
+        rc = lib.emul_stretch_block(ctypes.c_int64(1), ctypes.c_int64(pos.shape[0]), pos.shape[1], k, p(src, ctypes.c_int32), p(const, ctypes.c_double),
                                     p(fac, ctypes.c_double), p(lo, ctypes.c_double), p(hi, ctypes.c_double), int(fixed_ok),
                                     ctypes.c_int64(order.shape[0]), p(pos, ctypes.c_double), p(lnp, ctypes.c_double),
                                     p(order, ctypes.c_int32), p(zz, ctypes.c_double), p(thr, ctypes.c_double), p(pick, ctypes.c_int32),
@@ -103,3 +103,76 @@ def test_fixed_parameter_outside_its_bounds_rejects_everything():
                         block_fn=_block_fn(src, const, fac, lo, hi, False, calls))
     pos, lnp, _ = s.run_mcmc(start, 10, log_prob0=np.zeros(16))
     assert np.array_equal(pos, start) and not calls and np.all(s.acceptance_fraction == 0)
+
+
+def test_binned_block_equals_the_python_loop_of_the_binned_sampler():
+    """n_bins = B: B lock-stepped ensembles that share every evaluation (reference: one MCMC per radial bin,
+    bin/run_tests.py:75-124).  The library's block against the NumPy loop of analysis.binned.BinnedSampler, same draws."""
+    from mcmc_dynamics_amd.analysis.binned import BinnedSampler
+    lib = em.lib()
+    B, W, P = 5, 16, 4
+    lo, hi = np.array([0.2, -np.inf, -0.8, -np.inf]), np.array([np.inf, 1.5, 0.9, np.inf])
+    src, const, fac = np.arange(P, dtype=np.int32), np.zeros(P), np.ones(P)
+    shift = 0.3 * np.arange(B)[:, None]                       # every bin has its own posterior
+
+    def lnlike_rows(table, w):                                # (B * w, K) bin-major -> (B * w,)
+        t = np.asarray(table).reshape(B, w, -1)
+        return (-0.5 * ((t[..., 0] - 1.0 - shift) ** 2 / 0.5 + (t[..., 1] - 0.1 * t[..., 0] ** 2) ** 2 / 2.0 +
+                        np.sum(t[..., 2:] ** 2, axis=-1))).reshape(-1)
+
+    def lnprob(values):                                       # BinnedConstantFit.lnprob_batch for a box prior
+        v = np.asarray(values, dtype=np.float64)
+        flat = v.reshape(-1, P).copy()
+        ok = ~np.isnan(flat).any(axis=1) & (flat >= lo).all(axis=1) & (flat <= hi).all(axis=1)
+        out = np.full(flat.shape[0], -np.inf)
+        if ok.any():
+            flat[~ok] = flat[int(np.flatnonzero(ok)[0])]
+            out[ok] = lnlike_rows(flat, v.shape[1])[ok]
+        return out.reshape(B, v.shape[1])
+
+    sizes = []
+
+    @EVAL
+    def cb(tab, n, out):
+        sizes.append(n)
+        table = np.ctypeslib.as_array(tab, shape=(B * n, P))
+        np.ctypeslib.as_array(out, shape=(B * n,))[:] = lnlike_rows(table, n)
+        return 0
+
+    def block_fn(pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted):
+        p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t)) if a is not None else None
+        rc = lib.emul_stretch_block(ctypes.c_int64(B), ctypes.c_int64(W), P, P, p(src, ctypes.c_int32), p(const, ctypes.c_double),
+                                    p(fac, ctypes.c_double), p(lo, ctypes.c_double), p(hi, ctypes.c_double), 1,
+                                    ctypes.c_int64(order.shape[0]), p(pos, ctypes.c_double), p(lnp, ctypes.c_double),
+                                    p(order, ctypes.c_int32), p(zz, ctypes.c_double), p(thr, ctypes.c_double), p(pick, ctypes.c_int32),
+                                    p(chain, ctypes.c_double), p(lnprob_chain, ctypes.c_double), p(accepted, ctypes.c_int64), cb)
+        assert rc == 0, rc
+
+    rng = np.random.default_rng(4)
+    start = np.array([1.0, 0.3, 0.0, 0.0]) + 0.3 * rng.normal(size=(B, W, P)) + np.concatenate([shift, np.zeros((B, 3))], axis=1)[:, None, :]
+    start[..., 0] = np.abs(start[..., 0]) + 0.25
+    start[..., 2] = np.clip(start[..., 2], -0.7, 0.8)
+    start[..., 1] = np.minimum(start[..., 1], 1.4)
+    ref = BinnedSampler(B, W, P, lnprob, seed=9)
+    nat = BinnedSampler(B, W, P, lnprob, seed=9, block_fn=block_fn)
+    ref.block_steps = nat.block_steps = 16                    # several blocks in 40 steps
+    ref.run_mcmc(start, 40)
+    pos, lnp, _ = nat.run_mcmc(start, 40)
+    assert np.array_equal(nat.chain, ref.chain) and np.array_equal(nat.lnprobability, ref.lnprobability)
+    assert np.array_equal(nat.acceptance_fraction, ref.acceptance_fraction) and nat.chain.shape == (B, W, 40, P)
+    assert set(sizes) == {W // 2} and np.array_equal(pos, ref.chain[:, :, -1, :])
+    assert np.all(nat.chain[..., 0] >= 0.2) and np.all(nat.chain[..., 2] <= 0.9)
+    acc = nat.acceptance_fraction
+    assert 0.05 < acc.mean() < 0.95 and np.all(acc.reshape(B, -1).mean(axis=1) > 0.02)       # every bin moves
+    # the bins are independent chains: bin 2's chain does not change when the other bins start elsewhere
+    other = start.copy()
+    other[[0, 1, 3, 4]] += 0.05
+    other[..., 0] = np.maximum(other[..., 0], 0.25)
+    alt = BinnedSampler(B, W, P, lnprob, seed=9, block_fn=block_fn)
+    alt.block_steps = 16
+    alt.run_mcmc(other, 40)
+    assert np.array_equal(alt.chain[2], nat.chain[2]) and not np.array_equal(alt.chain[0], nat.chain[0])
+    # a second run continues from the state
+    ref.run_mcmc(ref.chain[:, :, -1, :], 7, log_prob0=ref.lnprobability[:, :, -1])
+    nat.run_mcmc(pos, 7, log_prob0=lnp)
+    assert np.array_equal(nat.chain, ref.chain) and nat.iteration == 47
