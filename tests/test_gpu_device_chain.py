@@ -294,7 +294,8 @@ def test_resident_chain_through_the_collective_path(native, kind):
     cat.close()
 
 
-def test_binned_ensembles_resident_equal_host_driven(native):
+@pytest.mark.parametrize("collective", [False, True])
+def test_binned_ensembles_resident_equal_host_driven(native, collective):
     """n_bins = B: one workgroup of the step kernel per ensemble (radial bin), one main-kernel launch of B x W/2 rows per
     half step, the guard judged on the table of all ensembles by the next launch.  Resident against host-driven, bit for
     bit; an ensemble without a single valid proposal makes the device give the block back."""
@@ -303,7 +304,16 @@ def test_binned_ensembles_resident_equal_host_driven(native):
     g = load_golden("radial_bins")
     reader = DataReader({k: g[k] for k in ("ra", "dec", "v", "verr")})
     reader.make_radial_bins(float(g["ra_center"]), float(g["dec_center"]), nstars=200, dlogr=0.05)
-    bf = BinnedConstantFit(reader)
+    context = None
+    if collective:                                                       # sums of B x W/2 rows and the status word through RCCL
+        import os
+        os.environ["MCD_FORCE_RCCL"] = "1"
+        try:
+            context = native.Context(rank=0, n_ranks=1, unique_id=native.Context.unique_id(), device=0)
+        finally:
+            del os.environ["MCD_FORCE_RCCL"]
+        assert context.comm_info()["size"] == 1
+    bf = BinnedConstantFit(reader, context=context)
     bf.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
     bf.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
     B, W, P = bf.n_bins, 40, 4
