@@ -224,6 +224,7 @@ struct mcd_catalog {
     int chain_consecutive = 0;         // discarded blocks in a row (the back-off doubles with each)
     int64_t chain_device_blocks = 0, chain_host_blocks = 0, chain_discarded = 0;
     int chain_last_status = 0;         // status word of the last discarded block (mcd::ChainStatus bits)
+    std::vector<hipEvent_t> chain_events;   // large blocks: parts joined by events (stretch_block_device)
     int last_prefetch = -1;            // the last main-kernel launch used the prefetching instantiation (-1: none yet)
 };
 
@@ -711,10 +712,22 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     std::memcpy(a.h + o_fac, d->col_factor, (size_t)K * 8);
     std::memcpy(a.h + o_lo, d->lo, (size_t)P * 8);
     std::memcpy(a.h + o_hi, d->hi, (size_t)P * 8);
-    big_copy(a.h + o_order, order, (size_t)n_steps * BW * 4);
-    big_copy(a.h + o_zz, zz, (size_t)n_steps * BW * 8);
-    big_copy(a.h + o_thr, thr, (size_t)n_steps * BW * 8);
-    big_copy(a.h + o_pick, pick, (size_t)n_steps * BW * 4);
+    // Blocks that move tens of MB (binned catalogues: the random numbers of 64 steps of 55 x 512 walkers are 40 MB, their
+    // chain rows 70 MB -- a third of the block's device time in copies) are cut into parts: the host copies and the PCIe
+    // transfers of one part overlap the device work of another (copies on the second stream, joined by events).
+    const size_t moved = (size_t)n_steps * BW * (24 + (chain ? (size_t)P * 8 : 0) + (lnprob_chain ? 8 : 0));
+    size_t part_threshold = (size_t)16 << 20;
+    if (const char* e = std::getenv("MCD_CHAIN_PART_BYTES")) part_threshold = (size_t)std::strtoull(e, nullptr, 10);   // testing aid
+    const int64_t n_parts = moved >= part_threshold ? std::min<int64_t>(4, n_steps) : 1;
+    auto part_begin = [&](int64_t k) { return n_steps * k / n_parts; };
+    auto copy_in = [&](int64_t i0, int64_t i1) {              // the random numbers of steps i0 .. i1: user -> pinned
+        const size_t at = (size_t)i0 * BW, n = (size_t)(i1 - i0) * BW;
+        big_copy(a.h + o_order + at * 4, order + at, n * 4);
+        big_copy(a.h + o_zz + at * 8, zz + at, n * 8);
+        big_copy(a.h + o_thr + at * 8, thr + at, n * 8);
+        big_copy(a.h + o_pick + at * 4, pick + at, n * 4);
+    };
+    if (n_parts == 1) copy_in(0, n_steps);
 
     // kernel family of this block: what the device's guard last asked for, else the verdict on the current positions
     int level = cat->chain_hint;
@@ -747,7 +760,6 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     sd.n_ok = (int32_t*)(a.d + o_nok); sd.ranges = (double*)(a.d + o_ranges);
     sd.table = w.d_params; sd.wpar = (double*)w.d_wpar;
 
-    MCD_HIP(hipMemcpyAsync(a.d, a.h, input_end, hipMemcpyHostToDevice, slot.stream));
     const bool coll = ctx->n_ranks > 1 || ctx->force_collective;
     mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, level, w.uniform_len, sh.n};
     shape.chunk_general = w.d_chunk_general;
@@ -766,38 +778,112 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     MCD_HIP(hipMemsetAsync(d_stamps, 0, 8 * 8 * 4096, slot.stream));
     sd.stamps = d_stamps;
 #endif
-    for (int64_t i = 0; i < n_steps; ++i)
-        for (int h = 0; h < 2; ++h) {
+    // launches of steps i0 .. i1; `mark` (may be null) is recorded right after the first step kernel, i.e. when the chain
+    // rows of every step before i0 are final (the row of step i0 - 1 is written by that launch)
+    auto enqueue_steps = [&](int64_t i0, int64_t i1, hipEvent_t mark) -> int {
+        for (int64_t i = i0; i < i1; ++i)
+            for (int h = 0; h < 2; ++h) {
 #ifdef MCD_CHAIN_STAMPS
-            sd.launch_index = i * 2 + h;
+                sd.launch_index = i * 2 + h;
 #endif
-            MCD_HIP(mcd::launch_stretch_step(slot.stream, sd, acc_step, acc_h, i, h, out_buf, prev_tag));
-            prev_tag = coll ? 0.0 : (double)(++cat->launch_seq);
-            shape.launch_tag = prev_tag;
-            MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, half));
-            MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, B, w.n_chunks, w.max_chunks_per_pset, half,
-                                       pset_const, out_buf));
-            if (coll) {
-                if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
-                MCD_NCCL(g_rccl.AllReduce(out_buf, out_buf, Bh, ncclDouble, ncclSum, slot.comm, slot.stream));
-                if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
+                MCD_HIP(mcd::launch_stretch_step(slot.stream, sd, acc_step, acc_h, i, h, out_buf, prev_tag));
+                if (mark && i == i0 && h == 0) MCD_HIP(hipEventRecord(mark, slot.stream));
+                prev_tag = coll ? 0.0 : (double)(++cat->launch_seq);
+                shape.launch_tag = prev_tag;
+                MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, half));
+                MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, B, w.n_chunks, w.max_chunks_per_pset, half,
+                                           pset_const, out_buf));
+                if (coll) {
+                    if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
+                    MCD_NCCL(g_rccl.AllReduce(out_buf, out_buf, Bh, ncclDouble, ncclSum, slot.comm, slot.stream));
+                    if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
+                }
+                acc_step = i;
+                acc_h = h;
             }
-            acc_step = i;
-            acc_h = h;
+        return MCD_OK;
+    };
+    auto finish = [&]() -> int {                               // the last accept [+ the collective status word]
+        MCD_HIP(mcd::launch_stretch_step(slot.stream, sd, acc_step, acc_h, -1, 0, out_buf, prev_tag));
+        if (coll) {
+            // ranks hold different shares of the catalogue, so their guard verdicts may differ: all discard the block if one does
+            double* status = (double*)(a.d + o_status);
+            MCD_HIP(mcd::launch_stretch_status(slot.stream, sd.meta, status));
+            if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
+            MCD_NCCL(g_rccl.AllReduce(status, status, 1, ncclDouble, ncclSum, slot.comm, slot.stream));
+            if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
         }
-    MCD_HIP(mcd::launch_stretch_step(slot.stream, sd, acc_step, acc_h, -1, 0, out_buf, prev_tag));
-    if (coll) {
-        // ranks hold different shares of the catalogue, so their guard verdicts may differ: all discard the block if one does
-        double* status = (double*)(a.d + o_status);
-        MCD_HIP(mcd::launch_stretch_status(slot.stream, sd.meta, status));
-        if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
-        MCD_NCCL(g_rccl.AllReduce(status, status, 1, ncclDouble, ncclSum, slot.comm, slot.stream));
-        if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupEnd());
+        return MCD_OK;
+    };
+    bool rows_delivered = false;                               // chain rows already in the caller's arrays (parts)
+    if (n_parts == 1) {
+        MCD_HIP(hipMemcpyAsync(a.d, a.h, input_end, hipMemcpyHostToDevice, slot.stream));
+        rc = enqueue_steps(0, n_steps, nullptr);
+        if (rc != MCD_OK) return rc;
+        rc = finish();
+        if (rc != MCD_OK) return rc;
+        MCD_HIP(hipMemcpyAsync(a.h, a.d, state_end, hipMemcpyDeviceToHost, slot.stream));
+        if (total > o_chain)
+            MCD_HIP(hipMemcpyAsync(a.h + o_chain, a.d + o_chain, total - o_chain, hipMemcpyDeviceToHost, slot.stream));
+        MCD_HIP(wait_stream(slot.stream, cat->spin_us));
+    } else {
+        // events: in[k] the numbers of part k are on the device; rows[k] the chain rows of part k are final; out[k] they
+        // are in pinned memory
+        while ((int64_t)cat->chain_events.size() < 3 * n_parts) {
+            hipEvent_t e;
+            MCD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            cat->chain_events.push_back(e);
+        }
+        hipEvent_t* ev_in = cat->chain_events.data();
+        hipEvent_t* ev_rows = ev_in + n_parts;
+        hipEvent_t* ev_out = ev_rows + n_parts;
+        auto rows_to_host = [&](int64_t k) -> int {            // D2H of part k's rows on the copy stream, behind rows[k]
+            const size_t at = (size_t)part_begin(k) * BW, n = (size_t)(part_begin(k + 1) - part_begin(k)) * BW;
+            MCD_HIP(hipStreamWaitEvent(slot.comm_stream, ev_rows[k], 0));
+            if (chain) MCD_HIP(hipMemcpyAsync(a.h + o_chain + at * P * 8, a.d + o_chain + at * P * 8, n * P * 8, hipMemcpyDeviceToHost, slot.comm_stream));
+            if (lnprob_chain) MCD_HIP(hipMemcpyAsync(a.h + o_lnpc + at * 8, a.d + o_lnpc + at * 8, n * 8, hipMemcpyDeviceToHost, slot.comm_stream));
+            MCD_HIP(hipEventRecord(ev_out[k], slot.comm_stream));
+            return MCD_OK;
+        };
+        auto rows_to_caller = [&](int64_t k) -> int {          // wait for out[k], pinned -> the caller's arrays
+            const size_t at = (size_t)part_begin(k) * BW, n = (size_t)(part_begin(k + 1) - part_begin(k)) * BW;
+            MCD_HIP(hipEventSynchronize(ev_out[k]));
+            if (chain) big_copy(chain + at * P, a.h + o_chain + at * P * 8, n * P * 8);
+            if (lnprob_chain) big_copy(lnprob_chain + at, a.h + o_lnpc + at * 8, n * 8);
+            return MCD_OK;
+        };
+        MCD_HIP(hipMemcpyAsync(a.d, a.h, o_order, hipMemcpyHostToDevice, slot.stream));   // state, column map, bounds
+        for (int64_t k = 0; k < n_parts; ++k) {
+            const int64_t i0 = part_begin(k), i1 = part_begin(k + 1);
+            const size_t at = (size_t)i0 * BW, n = (size_t)(i1 - i0) * BW;
+            copy_in(i0, i1);
+            MCD_HIP(hipMemcpyAsync(a.d + o_order + at * 4, a.h + o_order + at * 4, n * 4, hipMemcpyHostToDevice, slot.comm_stream));
+            MCD_HIP(hipMemcpyAsync(a.d + o_zz + at * 8, a.h + o_zz + at * 8, n * 8, hipMemcpyHostToDevice, slot.comm_stream));
+            MCD_HIP(hipMemcpyAsync(a.d + o_thr + at * 8, a.h + o_thr + at * 8, n * 8, hipMemcpyHostToDevice, slot.comm_stream));
+            MCD_HIP(hipMemcpyAsync(a.d + o_pick + at * 4, a.h + o_pick + at * 4, n * 4, hipMemcpyHostToDevice, slot.comm_stream));
+            MCD_HIP(hipEventRecord(ev_in[k], slot.comm_stream));
+            MCD_HIP(hipStreamWaitEvent(slot.stream, ev_in[k], 0));
+            rc = enqueue_steps(i0, i1, k > 0 ? ev_rows[k - 1] : nullptr);
+            if (rc != MCD_OK) return rc;
+            if (k > 0) {
+                rc = rows_to_host(k - 1);
+                if (rc != MCD_OK) return rc;
+                rc = rows_to_caller(k - 1);                     // (the device is busy with part k meanwhile)
+                if (rc != MCD_OK) return rc;
+            }
+        }
+        rc = finish();
+        if (rc != MCD_OK) return rc;
+        MCD_HIP(hipEventRecord(ev_rows[n_parts - 1], slot.stream));
+        MCD_HIP(hipMemcpyAsync(a.h, a.d, state_end, hipMemcpyDeviceToHost, slot.stream));
+        rc = rows_to_host(n_parts - 1);
+        if (rc != MCD_OK) return rc;
+        rc = rows_to_caller(n_parts - 1);
+        if (rc != MCD_OK) return rc;
+        MCD_HIP(wait_stream(slot.stream, cat->spin_us));
+        MCD_HIP(wait_stream(slot.comm_stream, cat->spin_us));
+        rows_delivered = true;   // (a discarded block leaves garbage there: the host-driven re-run overwrites every row)
     }
-    MCD_HIP(hipMemcpyAsync(a.h, a.d, state_end, hipMemcpyDeviceToHost, slot.stream));
-    if (total > o_chain)
-        MCD_HIP(hipMemcpyAsync(a.h + o_chain, a.d + o_chain, total - o_chain, hipMemcpyDeviceToHost, slot.stream));
-    MCD_HIP(wait_stream(slot.stream, cat->spin_us));
 #ifdef MCD_CHAIN_STAMPS
     {
         const int64_t n = std::min<int64_t>(n_steps * 2, 4096);
@@ -839,8 +925,8 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     std::memcpy(pos, a.h + o_pos, BW * P * 8);
     std::memcpy(lnp, a.h + o_lnp, BW * 8);
     if (accepted) std::memcpy(accepted, a.h + o_acc, BW * 8);
-    if (chain) big_copy(chain, a.h + o_chain, (size_t)n_steps * BW * P * 8);
-    if (lnprob_chain) big_copy(lnprob_chain, a.h + o_lnpc, (size_t)n_steps * BW * 8);
+    if (chain && !rows_delivered) big_copy(chain, a.h + o_chain, (size_t)n_steps * BW * P * 8);
+    if (lnprob_chain && !rows_delivered) big_copy(lnprob_chain, a.h + o_lnpc, (size_t)n_steps * BW * 8);
     *done = true;
     return MCD_OK;
 }
@@ -1109,6 +1195,7 @@ int mcd_catalog_destroy(mcd_catalog* cat) {
         if (sh.ev_end) (void)hipEventDestroy(sh.ev_end);
         for (auto& pr : sh.ring) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     }
+    for (hipEvent_t e : cat->chain_events) (void)hipEventDestroy(e);
     if (cat->chain.d) (void)hipFree(cat->chain.d);
     if (cat->chain.h) (void)hipHostFree(cat->chain.h);
     delete cat;

@@ -294,8 +294,43 @@ def test_resident_chain_through_the_collective_path(native, kind):
     cat.close()
 
 
+@pytest.fixture
+def blocks_in_parts(monkeypatch):
+    """Every resident block is cut into parts (what the library does from 16 MB of numbers and chain rows per block up:
+    host copies and transfers of one part overlap the device work of another)."""
+    monkeypatch.setenv("MCD_CHAIN_PART_BYTES", "1")
+
+
+@pytest.mark.parametrize("model,free", [(1, False), (2, True)])
+def test_blocks_cut_into_parts(native, ctx, blocks_in_parts, model, free):
+    rng = np.random.default_rng(9600 + model)
+    cat, sv = _catalogue(native, ctx, rng, 20011, model, free)
+    w = 32
+    pos = _walkers(rng, w, model, sv, free)
+    lo, hi = np.full(cat.k, -np.inf), np.full(cat.k, np.inf)
+    lo[1] = 0.0
+    if model == 2:
+        lo[-1], hi[-1] = 0.0, 1.0
+    plan = identity_plan(cat.k, lo, hi)
+    lnp = cat.loglike(pos)
+    for n_steps in (1, 3, 4, 13):                                      # fewer steps than parts, uneven parts
+        randoms = block_randoms(rng, n_steps, w, cat.k)
+        dev = run_block(cat, plan, pos, lnp, randoms, device=True)
+        assert same(dev, run_block(cat, plan, pos, lnp, randoms, device=False)), n_steps
+    info = cat.stretch_info()
+    assert info["device_blocks"] == 4 and info["discarded_blocks"] == 0, info
+    # chain rows not asked for: the parts still join up
+    randoms = block_randoms(rng, 6, w, cat.k)
+    cat.set_option("device_chain", 1)
+    p1, l1 = pos.copy(), lnp.copy()
+    cat.stretch_move(plan, p1, l1, *randoms)
+    ref = run_block(cat, plan, pos, lnp, randoms, device=False)
+    assert np.array_equal(p1, ref[0]) and np.array_equal(l1, ref[1])
+    cat.close()
+
+
 @pytest.mark.parametrize("collective", [False, True])
-def test_binned_ensembles_resident_equal_host_driven(native, collective):
+def test_binned_ensembles_resident_equal_host_driven(native, collective, blocks_in_parts):
     """n_bins = B: one workgroup of the step kernel per ensemble (radial bin), one main-kernel launch of B x W/2 rows per
     half step, the guard judged on the table of all ensembles by the next launch.  Resident against host-driven, bit for
     bit; an ensemble without a single valid proposal makes the device give the block back."""
