@@ -186,14 +186,14 @@ constexpr int kSmallPosBytes = 32 << 10;
 
 extern __shared__ double s_dynamic[];     // [W * P] positions | [W] log-probabilities | [W / 2] int32: the partner half
 
-template <int kMaxCols>
+template <int kMaxCols, bool kBinned>
 __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchDevice d, int64_t acc_step, int acc_h,
                                                                          int64_t prop_step, int prop_h,
                                                                          const double* __restrict__ ll, double rerun_tag) {
     const int half = (int)(d.n_walkers / 2), W = 2 * half, P = d.n_dim, K = d.k;
     const int j = threadIdx.x;
     // one workgroup per ensemble (radial bin): arrays carry the bin index in front of the walker index
-    const int64_t B = d.n_bins, b = blockIdx.x;
+    const int64_t B = kBinned ? d.n_bins : 1, b = kBinned ? blockIdx.x : 0;     // (one ensemble: no index arithmetic left)
     double* const pos_b = d.pos + b * W * P;
     double* const lnp_b = d.lnp + b * W;
     double* const proposal_b = d.proposal + b * half * P;
@@ -437,12 +437,14 @@ hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t ac
     const int cols = d.k > d.n_dim ? d.k : d.n_dim;
     const bool small = small_step(d);
     if (!small && d.n_bins != 1) return hipErrorInvalidValue;
-    if (small && cols <= 4)
-        hipLaunchKernelGGL(stretch_step_small_kernel<4>, dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
-    else if (small && cols <= 8)
-        hipLaunchKernelGGL(stretch_step_small_kernel<8>, dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
-    else if (small)
-        hipLaunchKernelGGL(stretch_step_small_kernel<12>, dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+#define MCD_LAUNCH_SMALL(C, BINNED)                                                                                            \
+    hipLaunchKernelGGL((stretch_step_small_kernel<C, BINNED>), dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, s, d, acc_step, \
+                       acc_h, prop_step, prop_h, ll, rerun_tag)
+    const bool binned = d.n_bins > 1;
+    if (small && cols <= 4) { if (binned) MCD_LAUNCH_SMALL(4, true); else MCD_LAUNCH_SMALL(4, false); }
+    else if (small && cols <= 8) { if (binned) MCD_LAUNCH_SMALL(8, true); else MCD_LAUNCH_SMALL(8, false); }
+    else if (small) { if (binned) MCD_LAUNCH_SMALL(12, true); else MCD_LAUNCH_SMALL(12, false); }
+#undef MCD_LAUNCH_SMALL
     else
         hipLaunchKernelGGL(stretch_step_kernel, dim3(1), dim3(kStepBlock), 0, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
     return hipGetLastError();
