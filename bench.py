@@ -607,7 +607,7 @@ def main():
         fit.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)
         fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
         rates = {}
-        for label, block_fn, n_mcmc in (("library", fit._stretch_block, 128), ("numpy_loop", None, 8)):
+        for label, block_fn, n_mcmc in (("library", fit._stretch_block, 256), ("numpy_loop", None, 8)):
             sampler = BinnedSampler(fit.n_bins, n_walkers, fit.n_fitted_parameters, fit.lnprob_batch, seed=5, block_fn=block_fn)
             state = sampler.run_mcmc(pos, 4 if block_fn is None else 70)
             t2 = time.perf_counter()
@@ -616,7 +616,7 @@ def main():
             acc = float(np.mean(sampler.acceptance_fraction))
         mcmc = {"steps_per_s": rates["library"], "terms_per_s": float(len(cat["v"])) * n_walkers * rates["library"],
                 "driver": "mcmc_dynamics_amd.analysis.binned.BinnedSampler", "posterior": "BinnedConstantFit.lnprob_batch",
-                "ensembles": fit.n_bins, "calls_per_step": 2, "walkers_per_call": n_walkers // 2, "steps": 128,
+                "ensembles": fit.n_bins, "calls_per_step": 2, "walkers_per_call": n_walkers // 2, "steps": 256,
                 "acceptance_fraction": acc, "numpy_loop_steps_per_s": rates["numpy_loop"],
                 "stretch_blocks": fit._catalog.stretch_info()}
         fit.close()

@@ -4,7 +4,8 @@
     python tools/fuzz_chain.py [--trials 300] [--seed 1] [--seconds 200] [--force-rccl]
 
 Random catalogues and ensembles over many orders of magnitude (tests/test_guard_random_cpu.py: random_case), all seven
-models, fixed and free centre, 4 .. 300 walkers, random box priors, random plans (fixed columns, unit factors).  The two
+models, fixed and free centre, 4 .. 300 walkers, random box priors, random plans (fixed columns, unit factors); every
+third case a binned catalogue (2 .. 6 ensembles in lockstep).  The two
 paths must agree in every bit of positions, log-probabilities, chain and acceptance counts -- whether the device keeps the
 block or gives it back -- and must raise the same error for a NaN.  Exit status 1 on any difference."""
 import argparse
@@ -23,9 +24,9 @@ from test_guard_random_cpu import CENTRE, random_case  # noqa: E402
 
 def run(cat, plan, pos, lnp, randoms, mode):
     cat.set_option("device_chain", mode)
-    n, w = randoms[0].shape
+    n = randoms[0].shape[0]
     p, l = pos.copy(), lnp.copy()
-    chain, lnpc, acc = np.empty((n,) + pos.shape), np.empty((n, w)), np.zeros(w, dtype=np.int64)
+    chain, lnpc, acc = np.empty((n,) + pos.shape), np.empty((n,) + lnp.shape), np.zeros(lnp.shape, dtype=np.int64)
     try:
         cat.stretch_move(plan, p, l, *randoms, chain, lnpc, acc)
     except native.NativeError as e:
@@ -47,7 +48,7 @@ def main():
     else:
         ctx = native.default_context()
     t0 = time.time()
-    total = bad = kept = discarded = errors = 0
+    total = bad = kept = discarded = errors = binned = 0
     reasons = {1: 0, 2: 0, 4: 0, 8: 0}
     for trial in range(a.trials):
         if time.time() - t0 > a.seconds:
@@ -81,6 +82,11 @@ def main():
                     params = np.hstack([params[:, :head], cc, params[:, head:]])
                     centre = None
                 k = params.shape[1]
+                # every third case: a binned catalogue (B radial bins = B lock-stepped ensembles sharing each evaluation)
+                n_bins = int(rng.integers(2, 7)) if trial % 3 == 1 and n >= 12 else 1
+                if n_bins > 1:
+                    edges = np.sort(rng.choice(np.arange(1, n), size=n_bins - 1, replace=False))
+                    kw["bin_offsets"] = np.concatenate([[0], edges, [n]]).astype(np.int64)
                 g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model, centre=centre, **kw)
                 assert g.k == k
                 # a plan: some kernel columns fixed at a walker's value, some sampled in other units
@@ -108,25 +114,36 @@ def main():
                     lo[src[1]] = max(lo[src[1]], 0.0)
                 plan = {"col_source": src, "col_const": const, "col_factor": np.where(fixed, 1.0, factor), "lo": lo, "hi": hi,
                         "fixed_ok": True}
-                table = np.where(src[None, :] >= 0, pos[:, np.maximum(src, 0)] * plan["col_factor"][None, :], const[None, :])
-                lnp = g.loglike(np.ascontiguousarray(table))
+                steps = int(rng.integers(1, 12))
+                half = w // 2
+                if n_bins > 1:
+                    # each ensemble a jittered copy of the walkers (inside the prior where the original is)
+                    jitter = 1.0 + 1e-3 * rng.normal(size=(n_bins,) + pos.shape)
+                    pos = np.ascontiguousarray(np.clip(pos[None] * jitter, np.where(np.isfinite(lo), lo, -np.inf), np.where(np.isfinite(hi), hi, np.inf)))
+                    flat = pos.reshape(-1, pos.shape[-1])
+                    table = np.where(src[None, :] >= 0, flat[:, np.maximum(src, 0)] * plan["col_factor"][None, :], const[None, :])
+                    lnp = np.ascontiguousarray(g.loglike(np.ascontiguousarray(table).reshape(n_bins, w, k)))
+                    lead = (n_bins,)
+                else:
+                    table = np.where(src[None, :] >= 0, pos[:, np.maximum(src, 0)] * plan["col_factor"][None, :], const[None, :])
+                    lnp = g.loglike(np.ascontiguousarray(table))
+                    lead = ()
                 if np.isnan(lnp).any():
                     g.close()
                     continue
-                steps = int(rng.integers(1, 12))
-                half = w // 2
-                order = np.argsort(rng.random((steps, w)), axis=1).astype(np.int32)
-                u = rng.random((steps, 4, half))
+                order = np.argsort(rng.random((steps,) + lead + (w,)), axis=-1).astype(np.int32)
+                u = rng.random((steps, 4) + lead + (half,))
                 zz = np.ascontiguousarray((u[:, :2] + 1.0) ** 2 / 2.0)
                 thr = np.ascontiguousarray(np.log(u[:, 2:]) - (free_cols.size - 1.0) * np.log(zz))
-                pick = rng.integers(0, half, size=(steps, 2, half)).astype(np.int32)
+                pick = rng.integers(0, half, size=(steps, 2) + lead + (half,)).astype(np.int32)
                 randoms = (order, zz, thr, pick)
                 before = g.stretch_info()
-                dev = run(g, plan, pos, lnp, randoms, 2 if trial % 5 == 4 else 1)
+                dev = run(g, plan, pos, lnp, randoms, 2 if trial % 5 == 4 and n_bins == 1 else 1)
                 info = g.stretch_info()
                 host = run(g, plan, pos, lnp, randoms, 0)
                 g.close()
                 total += 1
+                binned += n_bins > 1
                 if info["discarded_blocks"] > before["discarded_blocks"]:
                     discarded += 1
                     for bit in reasons:
@@ -144,7 +161,7 @@ def main():
         if trial % 10 == 0:
             print("trial", trial, "blocks", total, "bad", bad, "kept on device", kept, "given back", discarded, reasons,
                   "NaN errors", errors, "elapsed %.0f s" % (time.time() - t0), flush=True)
-    print("DONE blocks", total, "bad", bad, "kept on device", kept, "given back", discarded,
+    print("DONE blocks", total, "(binned:", binned, ") bad", bad, "kept on device", kept, "given back", discarded,
           "reasons (1 NaN, 2 re-run, 4 family, 8 no proposal):", reasons, "NaN errors", errors, flush=True)
     return 1 if bad else 0
 
