@@ -29,6 +29,8 @@ rm -rf $O/prof_${TAG}_chain
 timeout -k 10 200 python tools/chain_probe.py > $O/chain_probe_$TAG.txt 2>&1 || { tail -5 $O/chain_probe_$TAG.txt; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_chain -- python3 tools/chain_probe.py 1000000 256 64 > $O/prof_chain_$TAG.log 2>&1 || exit 1
 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 > $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
+MCD_CHAIN_PART_BYTES=1 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 7 >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
+timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 11 --force-rccl >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 echo "kernel traces done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/pmc_fetch_$TAG.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/pmc_write_$TAG.log 2>&1 || exit 1
