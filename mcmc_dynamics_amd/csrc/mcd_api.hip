@@ -632,12 +632,20 @@ void big_copy(void* dst, const void* src, size_t bytes) {
     constexpr int kThreads = 4;
     std::thread workers[kThreads - 1];
     const size_t part = (bytes / kThreads + 63) / 64 * 64;
+    int started = 0;
     for (int t = 1; t < kThreads; ++t) {
         const size_t at = std::min(bytes, part * t), len = std::min(bytes, part * (t + 1)) - at;
-        workers[t - 1] = std::thread([=] { if (len) std::memcpy((char*)dst + at, (const char*)src + at, len); });
+        try {
+            workers[t - 1] = std::thread([=] { if (len) std::memcpy((char*)dst + at, (const char*)src + at, len); });
+            ++started;
+        } catch (...) {                                        // no thread to be had: this share is copied here instead
+            if (len) std::memcpy((char*)dst + at, (const char*)src + at, len);
+        }
     }
     std::memcpy(dst, src, std::min(bytes, part));
-    for (auto& th : workers) th.join();
+    for (int t = 0; t < kThreads - 1; ++t)
+        if (workers[t].joinable()) workers[t].join();
+    (void)started;
 }
 
 int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
