@@ -252,6 +252,15 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
             for (int c = 0; c < kMaxCols; ++c) prev[c] = c < P ? proposal_b[j * P + c] : 0.0;
         }
     }
+    // several ensembles: workgroup 0 judges the guard on the table of all of them (below); the first kStepBlock ensembles'
+    // ranges are fetched with this round of loads, not behind the barrier
+    int first_n_ok = 0;
+    double first_ranges[10];
+    if (kBinned && b == 0 && do_acc && j < B) {
+        first_n_ok = d.n_ok[slot_acc + j];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) first_ranges[i] = d.ranges[(slot_acc + j) * 10 + i];
+    }
     int w_s = 0, pick_j = 0;
     double z_j = 0.0;
     if (do_prop && active) {
@@ -277,7 +286,8 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
             // the table of all ensembles?  (each workgroup of the previous launch left its ensemble's ranges in memory;
             // ensembles without a valid proposal raised CHAIN_NO_PROPOSAL themselves)
             ParamRanges mine;
-            for (int64_t e = j; e < B; e += kStepBlock)
+            if (j < B && first_n_ok > 0) mine.merge(load_ranges(first_ranges));
+            for (int64_t e = j + kStepBlock; e < B; e += kStepBlock)
                 if (d.n_ok[slot_acc + e] > 0) mine.merge(load_ranges(d.ranges + (slot_acc + e) * 10));
             wave_merge(mine);
             if ((j & 63) == 0) store_ranges(mine, s_ranges[j >> 6]);
