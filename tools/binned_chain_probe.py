@@ -17,10 +17,12 @@ fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
 B = fit.n_bins
 pos1 = synthetic.make_walkers(W, ["v_sys", "sigma_max", "v_maxx", "v_maxy"], cat["truth"], config=5)
 pos = np.ascontiguousarray(np.broadcast_to(pos1, (B,) + pos1.shape))
-s = BinnedSampler(B, W, 4, fit.lnprob_batch, seed=1, block_fn=fit._stretch_block)
-state = s.run_mcmc(pos, 70)
-t0 = time.perf_counter(); s.run_mcmc(state[0], 256, log_prob0=state[1]); dt = time.perf_counter() - t0
-print("B {0} W {1}: library blocks {2:.1f} us per step ({3:.0f} steps/s) {4}".format(B, W, dt / 256 * 1e6, 256 / dt, fit._catalog.stretch_info()), flush=True)
+for bs in (64, 128, 256):
+    s = BinnedSampler(B, W, 4, fit.lnprob_batch, seed=1, block_fn=fit._stretch_block)
+    s.block_steps = bs
+    state = s.run_mcmc(pos, bs + 6)
+    t0 = time.perf_counter(); s.run_mcmc(state[0], 512, log_prob0=state[1]); dt = time.perf_counter() - t0
+    print("B {0} W {1} block_steps {5}: library blocks {2:.1f} us per step ({3:.0f} steps/s) {4}".format(B, W, dt / 512 * 1e6, 512 / dt, fit._catalog.stretch_info(), bs), flush=True)
 half = W // 2
 tab = np.ascontiguousarray(np.broadcast_to(pos1[:half], (B, half, 4)))
 g = fit._catalog
@@ -43,3 +45,8 @@ chain, lnpc, acc = np.empty((64, B, W, 4)), np.empty((64, B, W)), np.zeros((B, W
 fit._stretch_block(p, l, *r, chain, lnpc, acc)
 t0 = time.perf_counter(); fit._stretch_block(p, l, *r, chain, lnpc, acc); dt = time.perf_counter() - t0
 print("library block of 64 steps alone: {0:.1f} us per step".format(dt / 64 * 1e6), flush=True)
+# the sampler's own cost: draws on four threads one block ahead, bookkeeping -- with a library call that does nothing
+s = BinnedSampler(B, W, 4, fit.lnprob_batch, seed=1, block_fn=lambda *a: None)
+state = s.run_mcmc(pos, 70)
+t0 = time.perf_counter(); s.run_mcmc(state[0], 512, log_prob0=state[1]); dt = time.perf_counter() - t0
+print("sampler without the library call: {0:.1f} us per step".format(dt / 512 * 1e6), flush=True)
