@@ -70,6 +70,10 @@ inline ChunkPlan plan_chunks(const std::vector<int64_t>& bin_offsets, int64_t st
     if (n_wtiles > 4) len = (5 * n * n_wtiles + 6 * target_waves - 1) / std::max<int64_t>(1, 6 * target_waves);
     else if (n_wtiles == 4) len = (n * n_wtiles + target_waves - 1) / std::max<int64_t>(1, target_waves);
     else len = (5 * n * n_wtiles / 4 + (target_waves * 3 / 5 - 136) - 1) / std::max<int64_t>(1, target_waves * 3 / 5 - 136);
+    // Several parameter sets (radial bins): only the LAST one gets the guided tail (the launch ends there; a tail of half-
+    // and quarter-length chunks at the end of each of 55 bins is 55 x the per-wave overhead for nothing), so the others
+    // need 1.25 x shorter chunks for the same number of waves.  C5 (55 bins x 512 walkers): 159.5 -> 145 us per step.
+    if (n_psets > 1) len = std::max<int64_t>(1, len * 4 / 5);
     if (chunk_len > 0) {
         len = std::max<int64_t>(64, (chunk_len + 31) / 32 * 32);   // explicit nominal length (option "chunk_len", tuning)
     } else {
@@ -87,7 +91,7 @@ inline ChunkPlan plan_chunks(const std::vector<int64_t>& bin_offsets, int64_t st
         const int64_t b0 = std::max(bin_offsets[p], star_begin);
         const int64_t b1 = std::min(bin_offsets[p + 1], star_begin + n);
         const int64_t total = b1 - b0;
-        const int mode = (total >= 16 * len && len >= 128) ? tail_split : 0;
+        const int mode = (total >= 16 * len && len >= 128 && p == n_psets - 1) ? tail_split : 0;
         const int64_t resident_chunks = std::max<int64_t>(1, 8192 / n_wtiles);
         for (int64_t s = b0; s < b1;) {
             const int64_t done = s - b0, rem = b1 - s;
