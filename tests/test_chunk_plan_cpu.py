@@ -177,3 +177,23 @@ def test_sharded_mixture_with_exception_stars_matches_the_oracle(n_shards):
     pos6 = np.column_stack([pos, np.full(96, CENTRE[0]), np.full(96, CENTRE[1])])
     got, _ = em.sharded_loglike(cat, pos6, 1, None, 2, n_shards, target_waves=512)
     np.testing.assert_allclose(got, want, rtol=1e-11)
+
+
+def test_binned_tables_keep_the_guided_tail_for_the_last_bin_only():
+    """Several parameter sets: equal-length chunks (1.25 x shorter than the un-binned length, for the same number of waves)
+    in every bin but the last, whose end is the end of the launch and keeps the half- / quarter-length tail."""
+    n, n_bins = 1000000, 20
+    offs = np.linspace(0, n, n_bins + 1).astype(np.int64)
+    plan = em.plan_chunks(offs, 0, n, 256, 10240, 1)
+    single = em.plan_chunks([0, n], 0, n, 256, 10240, 1)
+    assert plan["len"] < single["len"] and plan["len"] % 64 == 32
+    c, p = plan["count"], plan["pset"]
+    for b in range(n_bins - 1):
+        mine = c[p == b]
+        assert set(mine[:-1]) == {plan["len"]} and 0 < mine[-1] <= plan["len"], b            # equal chunks + a remainder
+    last = c[p == n_bins - 1]
+    assert last[0] == plan["len"] and {plan["len"] // 2 // 8 * 8, plan["len"] // 4 // 8 * 8} <= set(last), last
+    assert np.all(np.diff(last[:-1]) <= 0)
+    # a shard that does not hold the last bin has no tail at all
+    head = em.plan_chunks(offs, 0, n // 2, 256, 10240, 1)
+    assert set(np.unique(head["count"])) <= {head["len"]} | set(head["count"][np.r_[np.diff(head["pset"]) != 0, True]])
