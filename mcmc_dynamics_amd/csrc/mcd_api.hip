@@ -1351,10 +1351,14 @@ int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_step
     for (int c = 0; c < d->k; ++c)
         if (d->col_source[c] >= d->n_dim) return fail(MCD_ERR_INVALID, "mcd_stretch_move: col_source outside the free parameters");
     const int64_t W = d->n_walkers, half = W / 2;
-    for (int64_t i = 0; i < n_steps * B * W; ++i)
-        if (order[i] < 0 || order[i] >= W) return fail(MCD_ERR_INVALID, "mcd_stretch_move: order holds an index outside 0..W-1");
-    for (int64_t i = 0; i < n_steps * B * W; ++i)
-        if (pick[i] < 0 || pick[i] >= half) return fail(MCD_ERR_INVALID, "mcd_stretch_move: pick holds an index outside the half ensemble");
+    // (range checks as min / max reductions: branch-free, vectorised -- a binned block holds millions of indices)
+    auto within = [](const int32_t* a, int64_t n, int64_t bound) {
+        int32_t lo = 0, hi = 0;
+        for (int64_t i = 0; i < n; ++i) { lo = a[i] < lo ? a[i] : lo; hi = a[i] > hi ? a[i] : hi; }
+        return lo >= 0 && (int64_t)hi < bound;
+    };
+    if (!within(order, n_steps * B * W, W)) return fail(MCD_ERR_INVALID, "mcd_stretch_move: order holds an index outside 0..W-1");
+    if (!within(pick, n_steps * B * W, half)) return fail(MCD_ERR_INVALID, "mcd_stretch_move: pick holds an index outside the half ensemble");
     mcd::StretchDesc sd;
     sd.n_bins = B;
     sd.n_walkers = W; sd.n_dim = d->n_dim; sd.k = d->k; sd.col_source = d->col_source; sd.col_const = d->col_const;
