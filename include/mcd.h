@@ -200,8 +200,11 @@ int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t
  * waits for once -- no host round trip between two evaluations (option "device_chain", default 1; csrc/mcd_stretch.hip).
  * The numbers are the host-driven loop's, bit for bit.  What only the host loop can handle -- a NaN, a re-run request of
  * the fast mixture kernels, a proposal table for which the range guard picks another kernel family than was enqueued, a
- * half step with every proposal outside the prior -- makes the library discard the block and run it host-driven from
- * the same inputs; mcd_stretch_info counts both kinds. */
+ * half step with every proposal outside the prior (binned: an ensemble without a valid proposal) -- makes the library
+ * discard the block and run it host-driven from the same inputs; mcd_stretch_info counts both kinds.  pos, lnp and
+ * accepted are only ever written with final values; chain / lnprob_chain of a block that moves more than 16 MB are
+ * filled part by part while the device works on (a discarded block's rows are overwritten by its host-driven re-run).
+ * Binned catalogues run resident for ensembles of up to 512 walkers and 12 columns. */
 typedef struct {
     int64_t n_walkers;          /* W, even */
     int32_t n_dim;              /* free parameters (columns of pos) */
