@@ -132,7 +132,8 @@ class BinnedSampler(object):
             return out
 
         done = 0
-        chunk = max(1, int(self.block_steps))
+        # (blocks of very many ensembles are kept below ~8 M walker-steps: 200 MB of numbers in, 340 MB of rows out)
+        chunk = max(1, min(int(self.block_steps), (1 << 23) // (B * W)))
         pending = None
         while done < nsteps:
             n = min(chunk, nsteps - done)
