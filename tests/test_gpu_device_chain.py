@@ -410,3 +410,33 @@ def test_binned_ensembles_resident_equal_host_driven(native, collective, blocks_
     assert info["discarded_blocks"] == before["discarded_blocks"] + 1 and info["last_discard_status"] & 8, info
     assert same(dev3, run(0, far, far_lnp, r3)) and np.array_equal(dev3[0][2], far[2])
     bf.close()
+
+
+def test_hundreds_of_ensembles(native):
+    """More ensembles than the step kernel has threads (the guard's joint verdict loops over them), few walkers each."""
+    from mcmc_dynamics_amd import DataReader, synthetic
+    from mcmc_dynamics_amd.analysis import BinnedConstantFit
+    from mcmc_dynamics_amd.analysis.binned import BinnedSampler
+    cat = synthetic.make_catalog(40000, config=5)
+    reader = DataReader({k: cat[k] for k in ("ra", "dec", "v", "verr")})
+    reader.make_radial_bins(synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG, nstars=50, dlogr=0.002)
+    bf = BinnedConstantFit(reader)
+    bf.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)
+    bf.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
+    B = bf.n_bins
+    assert B > 300, B
+    pos1 = synthetic.make_walkers(16, ["v_sys", "sigma_max", "v_maxx", "v_maxy"], cat["truth"], config=5)
+    pos = np.ascontiguousarray(np.broadcast_to(pos1, (B,) + pos1.shape)) * (1.0 + 1e-3 * np.random.default_rng(3).normal(size=(B, 16, 4)))
+    pos[..., 1] = np.abs(pos[..., 1])
+    res = []
+    for mode in (1, 0):
+        s = BinnedSampler(B, 16, 4, bf.lnprob_batch, seed=8, block_fn=bf._stretch_block)
+        s.block_steps = 5
+        bf._ensure_catalog().set_option("device_chain", mode)
+        s.run_mcmc(pos, 12)
+        res.append((s.chain.copy(), s.lnprobability.copy(), s.acceptance_fraction.copy()))
+        s.close()
+    info = bf._catalog.stretch_info()
+    assert info["device_blocks"] == 3 and info["host_blocks"] == 3 and info["discarded_blocks"] == 0, info
+    assert all(np.array_equal(a, b) for a, b in zip(*res)) and np.all(np.isfinite(res[0][1]))
+    bf.close()
