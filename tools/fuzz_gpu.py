@@ -5,7 +5,13 @@ tests/test_gpu_kernels.py::test_fast_and_plain_kernels_agree_over_wide_ranges).
 
 For every model (fixed and free centre) random catalogues / walker tables spanning many orders of magnitude are evaluated
 with the guarded fast path and with the plain (reference-literal) kernels; any disagreement in the finite / -inf pattern
-or beyond 1e-11 relative is printed with its seed.  Exit status 1 if any trial disagreed."""
+or beyond 1e-11 relative is printed with its seed.  Exit status 1 if any trial disagreed.
+
+Float32 modes compare the float32 fast formulations with the plain float32 kernels: a consistency check between two
+approximations, with the tolerance at the accuracy floor of the less accurate one -- which is the plain kernel (its
+literal log-sum-exp in float32: seed 36136862, model 2, f32acc64, deviates 3.0e-5 from the float64 value where the fast
+formulation deviates 9e-8).  Accuracy against float64 on realistic ranges is what tests/test_gpu_baseline_shapes.py and
+test_precision_sweep_c5 assert."""
 import argparse
 import os
 import sys
@@ -29,7 +35,7 @@ def main():
     ap.add_argument("--max-walkers", type=int, default=200, help="> 256 exercises the XCD-aware workgroup mapping")
     ap.add_argument("--schedule", action="store_true", help="also randomise target_waves / tail_split per case")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32acc64", "f32"],
-                    help="float32 modes compare the float32 fast formulations with the plain float32 kernels (tolerance 2e-5 / 5e-4)")
+                    help="float32 modes compare the float32 fast formulations with the plain float32 kernels (tolerance 5e-5 / 5e-4)")
     ap.add_argument("--force-rccl", action="store_true",
                     help="1-rank communicator (MCD_FORCE_RCCL=1): the collective code path, where the re-run signal travels "
                          "as NaN-poisoned partial sums through the all-reduce")
@@ -99,7 +105,7 @@ def main():
                 admitted_inf += int(np.isneginf(plain).sum())
                 if err > worst:
                     worst, worst_case = err, (seed, model, free, n, w, g_level)
-                if not same or err > {"f64": 1e-11, "f32acc64": 2e-5, "f32": 5e-4}[a.precision]:
+                if not same or err > {"f64": 1e-11, "f32acc64": 5e-5, "f32": 5e-4}[a.precision]:
                     bad += 1
                     print("MISMATCH seed", seed, "model", model, "free", free, "n", n, "w", w, "pattern_same", same, "err", err,
                           flush=True)
