@@ -132,7 +132,9 @@ struct WorkSet {
     int64_t n_walkers = 0;
     int64_t n_chunks = 0;
     int64_t max_chunks_per_pset = 0;
-    int uniform_len = 0;               // > 0 when the chunk table is arithmetic (single set, equal lengths)
+    int uniform_len = 0;               // > 0 when the chunk table is arithmetic (single set; mcd_chunks.h: uniform_chunk)
+    int uniform_extra = 0;
+    int waves = 4;                     // 8: balanced plan whose workgroups combine their chunks' sums (f64 fast kernels only)
     mcd::Chunk* d_chunks = nullptr;
     int64_t* d_offsets = nullptr;      // [n_psets + 1] chunk offsets
     uint8_t* d_chunk_general = nullptr;   // [n_chunks] chunks excluded from the narrow-range variant; null when there are none
@@ -209,6 +211,10 @@ struct mcd_catalog {
     int64_t target_waves = 10240;      // see mcd_chunks.h: plan_chunks
     int64_t chunk_len = 0;             // option "chunk_len": explicit nominal chunk length (0: from target_waves)
     int prefetch = -1;                 // option "prefetch": -1 by record volume (>= 8 MiB per device), 0 off, 1 on
+    int balance = -1;                  // option "balance": one round of equal waves (mcd_chunks.h): -1 when the catalogue is
+                                       // small enough, 0 never, m > 0 forced with m workgroups per CU
+    int combine = 1;                   // option "combine": balanced plans may use 8- / 16-wave workgroups that combine their
+                                       // chunks' sums: 0 never, 1 the largest the plan allows, 8 / 16 at most that many waves
     // state of the last evaluation
     int64_t cur_walkers = 0;
     double last_kernel_ms = -1.0, last_device_ms = -1.0;
@@ -218,6 +224,8 @@ struct mcd_catalog {
     int64_t n_reruns = 0;              // batches re-evaluated with the plain kernels (denormal regime of the reference)
     // resident stretch-move chain (mcd_stretch.hip)
     int device_chain = 1;              // option "device_chain": 0 host-driven blocks only
+    int fused_reduce = 1;              // option "fused_reduce": the step kernel adds up small launches' partial sums itself
+    bool chain_last_fused = false;
     ChainArena chain;
     int chain_hint = -1;               // kernel family the device's guard asked for when it last disagreed (-1: none)
     int64_t chain_backoff = 0;         // blocks left to run host-driven after a discarded block
@@ -256,6 +264,27 @@ void free_workset(WorkSet& w) {
     w = WorkSet();
 }
 
+// Which catalogues get ONE round of equal waves (mcd_chunks.h: balanced plans) and with how many workgroups per CU.
+// Measured on MI355X (tools/balance_sweep.py, us per pipelined step = main kernel + reduction; multi-round schedule /
+// best balanced plan): CONST x 256 walkers 1e4 stars 7.9 / 6.7, 3e4 9.7 / 8.8, 1e5 19.2 / 13.3, 2e5 27.4 / 20.3, 4e5
+// 40.7 / 33.3, 8e5 67.0 / 63.3, 1.25e6 94.2 / 95.2;  BGFIXED x 256: 1e4 18.1 / 9.1, 1e5 38.1 / 28.5, 4e5 94.0 / 89.7,
+// 6e5 129.5 / 130.7, 1e6 202 / 213;  BGGAUSS 1e5 x 256 58.1 / 46.4;  x 128 walkers: CONST 1e5 15.4 / 9.7, BGFIXED 27.5 /
+// 18.0.  Small catalogues gain because every CU gets the same number of workgroups (1042 workgroups land as 4 or 5 per
+// CU, and the launch waits for the CUs with 5) and because the workgroups add up their chunks' sums themselves; beyond
+// ~1e6 CONST-equivalent stars per 256 walkers the dynamic balancing of 1.5 rounds with a guided tail wins.
+// "work" = stars x (walker tiles / 4) x (instructions per term / those of CONST): the thresholds are in CONST stars.
+double model_cost(int model, bool free_centre) {
+    static const double kCost[mcd::kNumModels] = {8.5, 24.0, 45.0, 25.0, 60.0, 40.0, 42.0};   // fast f64 loops, DESIGN 3.3
+    return (kCost[model] + (free_centre ? 7.0 : 0.0)) / 8.5;
+}
+int balance_auto_m(const mcd_catalog* cat, int64_t n, int64_t n_walkers) {
+    const int64_t n_wtiles = (n_walkers + 63) / 64;
+    const double tiles = n_wtiles <= 4 ? (double)n_wtiles : 4.0 * (double)((n_wtiles + 3) / 4);
+    const double work = (double)n * tiles / 4.0 * model_cost(cat->model, cat->free_centre);
+    if (cat->n_psets != 1 || work > 1.1e6) return 0;
+    return work < 6.0e4 ? 2 : (work <= 3.4e5 ? 4 : 8);
+}
+
 // Work buffers of one shard for a given walker count; the chunk table itself is planned by mcd_chunks.h: plan_chunks
 // (host-only, unit-tested on the CPU).
 int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out) {
@@ -269,8 +298,14 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     const DeviceSlot& slot = cat->ctx->slots[sh.slot];
     MCD_HIP(hipSetDevice(slot.device));
 
-    const mcd::ChunkPlan plan = mcd::plan_chunks(cat->bin_offsets, sh.star_begin, sh.n, n_walkers, cat->target_waves,
-                                                 cat->tail_split, cat->stats.narrow_exceptions, cat->chunk_len);
+    // balanced single-round plan where it pays (option "balance": -1 by the rule above, 0 never, m forced); a catalogue
+    // too small for m workgroups per CU (fewer than 16 stars per chunk) takes half as many, down to the multi-round table
+    mcd::ChunkPlan plan;
+    for (int m = cat->balance < 0 ? balance_auto_m(cat, sh.n, n_walkers) : cat->balance;; m /= 2) {
+        plan = mcd::plan_chunks(cat->bin_offsets, sh.star_begin, sh.n, n_walkers, cat->target_waves, cat->tail_split,
+                                cat->stats.narrow_exceptions, cat->chunk_len, m);
+        if (m == 0 || plan.balanced_m > 0) break;
+    }
     const std::vector<mcd::Chunk>& chunks = plan.chunks;
     const std::vector<int64_t>& offs = plan.offsets;
     const std::vector<uint8_t>& general = plan.general;
@@ -280,6 +315,24 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
     w.n_chunks = (int64_t)chunks.size();
     w.max_chunks_per_pset = plan.max_chunks_per_pset;
     w.uniform_len = plan.uniform_len;
+    w.uniform_extra = plan.uniform_extra;
+    {
+        // balanced plans with an even number of workgroups per CU run as half as many 8-wave workgroups that add their
+        // chunks' sums up themselves: half (to an eighth of) the partial sums per walker (mcd_kernels.hip: loglike_kernel)
+        const int64_t n_wtiles = (n_walkers + 63) / 64;
+        const bool shape_ok = plan.balanced_m > 0 && plan.balanced_m % 2 == 0 && (n_wtiles == 1 || n_wtiles == 2 || n_wtiles == 4) &&
+                              cat->precision == MCD_F64;
+        w.waves = 4;
+        if (cat->combine != 0 && shape_ok) {
+            // 4 workgroups per CU as one 16-wave workgroup: 256 partial sums per walker, which the resident chain's step
+            // kernel adds up itself (mcd_stretch.hip) -- 3 - 6 % slower than two 8-wave workgroups, one kernel less per
+            // half step; 8 per CU stay 8-wave workgroups (1e5 stars x 256 walkers: 14.5 us per step against 15.1)
+            const bool can16 = mcd::bg_kind(cat->model) != mcd::BG_GAUSS;
+            w.waves = 8;
+            if (cat->combine == 16 && plan.balanced_m % 4 == 0 && can16) w.waves = 16;
+            if (cat->combine == 1 && plan.balanced_m == 4 && can16) w.waves = 16;
+        }
+    }
     const int64_t padded_walkers = (n_walkers + 63) / 64 * 64;       // partial sums: whole walker tiles (mcd_kernels.hip)
     const int64_t n_out = cat->n_psets * n_walkers;
     const size_t term_bytes = cat->precision == MCD_F64 ? 8 : 4;
@@ -437,6 +490,8 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
         const DeviceSlot& slot = ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, w.fast, w.uniform_len, sh.n};
+        shape.uniform_extra = w.uniform_extra;
+        shape.waves = w.waves;
         // Re-run signal of the fast mixture kernels.  One device: a flag word behind the outputs receives a fresh tag per
         // launch (no reset needed).  Several ranks / devices: the kernels poison the affected partial sums with NaN
         // instead, which travels through the reduce kernel and the all-reduce to every rank.
@@ -457,7 +512,6 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
         shape.chunk_general = w.d_chunk_general;
         // records beyond what the caches hold between two passes: prefetch the next loop iteration's records (mcd_math.h)
         shape.prefetch = wants_prefetch(cat, sh);
-    cat->last_prefetch = shape.prefetch && shape.fast != 0;
         cat->last_prefetch = shape.prefetch && shape.fast != 0;
         shape.rerun_flag = coll ? nullptr : out_buf + n_out;
         w.launch_tag = coll ? 0.0 : (double)(++cat->launch_seq);
@@ -485,8 +539,11 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
         const int bgk = mcd::bg_kind(cat->model);
         const double* pset_const =
             (w.fast && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
-        MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, w.n_chunks,
-                                   w.max_chunks_per_pset, W, pset_const, out_buf));
+        {
+            const int64_t n_slots = mcd::partial_slots(shape, w.n_chunks, W);
+            MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, n_slots,
+                                       cat->n_psets == 1 ? n_slots : w.max_chunks_per_pset, W, pset_const, out_buf));
+        }
         if (coll && pipelined) MCD_HIP(hipEventRecord(w.ev_reduced[w.buf], slot.stream));
     }
     // sum the per-device / per-rank partial log-likelihoods: one all-reduce of n_out doubles
@@ -534,7 +591,10 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
     {
         WorkSet& w0 = (*find_work(cat->shards[0], W));
         cat->last_chunks = w0.n_chunks;
-        cat->last_grid = mcd::main_grid(w0.n_chunks, W);
+        mcd::LaunchShape sh0{cat->model, cat->free_centre, cat->precision, w0.fast};
+        sh0.waves = w0.waves;
+        const int64_t slots = mcd::partial_slots(sh0, w0.n_chunks, W);
+        cat->last_grid = slots != w0.n_chunks ? slots : mcd::main_grid(w0.n_chunks, W);
     }
     return MCD_OK;
 }
@@ -773,6 +833,8 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
 
     const bool coll = ctx->n_ranks > 1 || ctx->force_collective;
     mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, level, w.uniform_len, sh.n};
+    shape.uniform_extra = w.uniform_extra;
+    shape.waves = w.waves;
     shape.chunk_general = w.d_chunk_general;
     shape.prefetch = wants_prefetch(cat, sh);
     cat->last_prefetch = shape.prefetch && shape.fast != 0;
@@ -780,6 +842,18 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     shape.rerun_flag = coll ? nullptr : out_buf + Bh;
     const int bgk = mcd::bg_kind(cat->model);
     const double* pset_const = (level && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
+    // launches with few partial sums per walker (balanced plans of small catalogues, radial bins of a few chunks): no
+    // reduction kernel, the step kernel adds them up itself -- the same code in the same order (mcd_reduce.h), so the
+    // chain keeps the bits of the host-driven loop.  Not with a collective: the all-reduce needs the sums in memory.
+    const int64_t n_slots = mcd::partial_slots(shape, w.n_chunks, half);
+    const int64_t max_slots = B == 1 ? n_slots : w.max_chunks_per_pset;
+    const bool fused = cat->fused_reduce != 0 && !coll && max_slots <= mcd::kFusedReduceSlots && mcd::stretch_step_fuses(sd);
+    sd.fused = fused ? 1 : 0;
+    sd.partials = w.d_partials;
+    sd.n_slots = n_slots;
+    sd.slot_offsets = B == 1 ? nullptr : w.d_offsets;
+    sd.pset_const = pset_const;
+    cat->chain_last_fused = fused;
     double prev_tag = 0.0;
     int64_t acc_step = -1;
     int acc_h = 0;
@@ -802,8 +876,9 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
                 prev_tag = coll ? 0.0 : (double)(++cat->launch_seq);
                 shape.launch_tag = prev_tag;
                 MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, half));
-                MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, B, w.n_chunks, w.max_chunks_per_pset, half,
-                                           pset_const, out_buf));
+                if (!fused)
+                    MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, B, n_slots, max_slots, half, pset_const,
+                                               out_buf));
                 if (coll) {
                     if (!ctx->multi_process) MCD_NCCL(g_rccl.GroupStart());
                     MCD_NCCL(g_rccl.AllReduce(out_buf, out_buf, Bh, ncclDouble, ncclSum, slot.comm, slot.stream));
@@ -918,7 +993,10 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     w.fast = level;
     cat->cur_walkers = half;
     cat->last_chunks = w.n_chunks;
-    cat->last_grid = mcd::main_grid(w.n_chunks, half);
+    {
+        const int64_t slots = mcd::partial_slots(shape, w.n_chunks, half);
+        cat->last_grid = slots != w.n_chunks ? slots : mcd::main_grid(w.n_chunks, half);
+    }
     const int32_t* meta = (const int32_t*)(a.h + o_meta);
     const bool discard = meta[mcd::META_STATUS] != 0 || (coll && *(const double*)(a.h + o_status) != 0.0);
     if (discard) {
@@ -1441,6 +1519,7 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         cat->chain_hint = -1;
         return MCD_OK;
     }
+    if (!std::strcmp(key, "fused_reduce")) { cat->fused_reduce = value != 0; return MCD_OK; }
     if (!std::strcmp(key, "prefetch")) {
         if (value < -1 || value > 1) return fail(MCD_ERR_INVALID, "prefetch: -1 (by record volume, default), 0 (off) or 1 (on)");
         cat->prefetch = (int)value;
@@ -1451,14 +1530,21 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         cat->spin_us = value;
         return MCD_OK;
     }
-    if (!std::strcmp(key, "tail_split") || !std::strcmp(key, "target_waves") || !std::strcmp(key, "chunk_len")) {
+    if (!std::strcmp(key, "tail_split") || !std::strcmp(key, "target_waves") || !std::strcmp(key, "chunk_len") ||
+        !std::strcmp(key, "balance") || !std::strcmp(key, "combine")) {
         const bool is_split = !std::strcmp(key, "tail_split"), is_len = !std::strcmp(key, "chunk_len");
-        if (!is_split && !is_len && value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");
+        const bool is_bal = !std::strcmp(key, "balance"), is_comb = !std::strcmp(key, "combine");
+        if (!std::strcmp(key, "target_waves") && value <= 0) return fail(MCD_ERR_INVALID, "target_waves must be positive");
         if (is_len && value < 0) return fail(MCD_ERR_INVALID, "chunk_len must be >= 0");
+        if (is_bal && (value < -1 || value > 8)) return fail(MCD_ERR_INVALID, "balance: -1 (auto), 0 (off) or 1 .. 8 workgroups per CU");
+        if (is_comb && value != 0 && value != 1 && value != 8 && value != 16)
+            return fail(MCD_ERR_INVALID, "combine: 0 (never), 1 (largest workgroup the plan allows), 8 or 16 (waves per workgroup at most)");
         int rc = sync_all(cat);
         if (rc != MCD_OK) return rc;
         if (is_split) cat->tail_split = (int)value;
         else if (is_len) cat->chunk_len = value;
+        else if (is_bal) cat->balance = (int)value;
+        else if (is_comb) cat->combine = (int)value;
         else cat->target_waves = value;
         for (Shard& sh : cat->shards) {            // chunk tables depend on it: rebuild lazily
             (void)hipSetDevice(cat->ctx->slots[sh.slot].device);

@@ -38,8 +38,40 @@ struct ChunkPlan {
     std::vector<uint8_t> general;       // per chunk: holds a narrow_exception star (empty when no chunk does)
     int64_t max_chunks_per_pset = 0;
     int64_t len = 0;                    // nominal chunk length
-    int uniform_len = 0;                // > 0: chunk c covers records [c len, min((c + 1) len, n)) of parameter set 0
+    int uniform_len = 0;                // > 0: the table is arithmetic (uniform_chunk below), parameter set 0 only
+    int uniform_extra = 0;              // the first `uniform_extra` chunks hold uniform_len + 8 stars (balanced plans)
+    int balanced_m = 0;                 // > 0: one round of equal waves, this many workgroups per CU (balanced_chunk_count)
 };
+
+// Chunk c of an arithmetic table: the first `extra` chunks hold len + 8 stars, the others len, the last one whatever is
+// left (legacy equal-length tables: extra = 0 and a shorter last chunk; balanced tables: the n % 8 odd stars).  The main
+// kernel computes the same three lines (mcd_kernels.hip) instead of waiting for a descriptor load.
+inline Chunk uniform_chunk(int64_t c, int64_t len, int64_t extra, int64_t n, int64_t n_chunks) {
+    Chunk ch;
+    ch.begin = c * len + 8 * std::min(c, extra);
+    ch.count = (int32_t)(c == n_chunks - 1 ? n - ch.begin : len + (c < extra ? 8 : 0));
+    ch.pset = 0;
+    return ch;
+}
+
+constexpr int64_t kNumCUs = 256;        // MI355X: 8 XCDs x 32 CUs, 4 SIMDs each
+
+// One round of EQUAL waves for catalogues whose whole launch fits the resident wave slots (8 per SIMD): the number of
+// chunks G such that every CU receives exactly `m` workgroups (the dispatcher deals a fresh grid evenly: measured with
+// per-workgroup timestamps, tools/main_stamps_probe.py -- 1042 workgroups land as 4 or 5 per CU, and the CUs with 5 finish
+// 25 % later).  Device timestamps at 1e5 stars x 256 walkers (CONST): a lone wave per SIMD needs 0.56 us per 16-star
+// iteration, two waves 0.66 us each (0.33 us per iteration for the SIMD), four or five waves no less -- two waves per
+// SIMD saturate the f64 pipe, more waves only add their ~100-instruction prologue and epilogue (the final log) per wave.
+//   n_wtiles 1, 2, 4: a workgroup's four waves cover 4, 2, 1 chunks      -> G = 256 m (4 / n_wtiles)
+//   n_wtiles 3:       workgroups straddle chunks                           -> G = ceil(1024 m / 3)
+//   n_wtiles > 4:     a chunk needs mb = ceil(n_wtiles / 4) workgroups     -> G = 256 m / mb, a multiple of 8 (XCD grouping)
+inline int64_t balanced_chunk_count(int64_t n_wtiles, int64_t m) {
+    if (n_wtiles <= 0 || m <= 0) return 0;
+    if (n_wtiles == 3) return (4 * kNumCUs * m + 2) / 3;
+    if (n_wtiles <= 4) return kNumCUs * m * (4 / n_wtiles);
+    const int64_t mb = (n_wtiles + 3) / 4;
+    return std::max<int64_t>(8, kNumCUs * m / mb / 8 * 8);
+}
 
 // Chunk table of the shard [star_begin, star_begin + n) of a catalogue whose parameter sets (radial bins) are the
 // global star ranges bin_offsets[p] .. bin_offsets[p + 1]; a bin that straddles the shard edge contributes its local
@@ -53,10 +85,33 @@ struct ChunkPlan {
 //   * narrow_exceptions: ascending GLOBAL star indices (mcd_guard.h)
 inline ChunkPlan plan_chunks(const std::vector<int64_t>& bin_offsets, int64_t star_begin, int64_t n, int64_t n_walkers,
                              int64_t target_waves, int tail_split, const std::vector<int64_t>& narrow_exceptions,
-                             int64_t chunk_len = 0) {
+                             int64_t chunk_len = 0, int balance = 0) {
     ChunkPlan plan;
     const int64_t n_psets = (int64_t)bin_offsets.size() - 1;
     const int64_t n_wtiles = (n_walkers + 63) / 64;
+    // ---- one round of equal waves: `balance` = workgroups per CU (0: the multi-round schedules below; which catalogues
+    // take it is the caller's rule, mcd_api.hip: balance_auto_m) ----
+    if (balance > 0 && n_psets == 1 && chunk_len == 0 && n > 0 && bin_offsets[0] <= star_begin &&
+        bin_offsets[1] >= star_begin + n) {
+        const int64_t m = std::min<int64_t>(balance, 8);
+        const int64_t G = balanced_chunk_count(n_wtiles, m);
+        const int64_t q = G > 0 ? n / G / 8 * 8 : 0;
+        if (q >= 16 && q + 8 < kMaxChunkLen) {
+            const int64_t extra = (n - G * q) / 8;
+            plan.len = q;
+            plan.uniform_len = (int)q;
+            plan.uniform_extra = (int)extra;
+            plan.balanced_m = (int)m;
+            plan.chunks.reserve((size_t)G);
+            for (int64_t c = 0; c < G; ++c) plan.chunks.push_back(uniform_chunk(c, q, extra, n, G));
+            plan.offsets = {0, G};
+            plan.max_chunks_per_pset = G;
+        }
+    }
+    if (!plan.chunks.empty()) {
+        // (flags below)
+    } else {
+    plan = ChunkPlan();
     // 256 walkers: `target_waves` full-length waves (default 10240 = 1.25 full-occupancy sets of 256 CUs x 4 SIMDs x 8
     // waves), i.e. ~1.5 rounds of resident waves once the guided tail is added; more than 256 walkers (several workgroups
     // per chunk): 1.2 x that (C5, 55 bins x 512 walkers: 158.6 us per step against 162.6).  <= 192 walkers (a workgroup's
@@ -113,11 +168,13 @@ inline ChunkPlan plan_chunks(const std::vector<int64_t>& bin_offsets, int64_t st
     plan.offsets[n_psets] = (int64_t)plan.chunks.size();
     if (n_psets == 1 && !plan.chunks.empty() && len < (int64_t)1 << 30) {
         bool uniform = true;
-        for (size_t i = 0; i < plan.chunks.size() && uniform; ++i)
-            uniform = plan.chunks[i].begin == (int64_t)i * len &&
-                      plan.chunks[i].count == (int32_t)std::min<int64_t>(len, n - (int64_t)i * len);
+        for (size_t i = 0; i < plan.chunks.size() && uniform; ++i) {
+            const Chunk u = uniform_chunk((int64_t)i, len, 0, n, (int64_t)plan.chunks.size());
+            uniform = plan.chunks[i].begin == u.begin && plan.chunks[i].count == u.count;
+        }
         if (uniform) plan.uniform_len = (int)len;
     }
+    }   // (multi-round schedules)
     if (!narrow_exceptions.empty()) {
         plan.general.assign(plan.chunks.size(), 0);
         bool any = false;

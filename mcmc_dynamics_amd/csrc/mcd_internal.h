@@ -14,8 +14,12 @@ struct LaunchShape {
     bool free_centre;
     int precision;    // mcd_precision
     int fast;         // 0 plain; 1 product/fraction-tree path (range guard passed); 2 narrow-range BGFIXED variant
-    int uniform_len = 0;     // > 0: chunk c covers records [c * len, min((c + 1) * len, n_records)) of parameter set 0
+    int uniform_len = 0;     // > 0: arithmetic chunk table of parameter set 0 (mcd_chunks.h: uniform_chunk)
     int64_t n_records = 0;
+    int uniform_extra = 0;   // its first `uniform_extra` chunks hold uniform_len + 8 stars
+    int waves = 4;           // waves per workgroup of the main kernel: 4, or 8 / 16 = the workgroup combines its chunks' sums
+                             // (f64 fast kernels, <= 256 walkers in 1, 2 or 4 tiles; 16 not for the BG_GAUSS models;
+                             // partial_slots() below)
     const uint8_t* chunk_general = nullptr;   // fast == 2: chunks that must take the general fast form (hold a star that
                                               // rules out the narrow-range variant, mcd_guard.h: narrow_exception); may be null
     bool prefetch = false;          // software prefetch of the next iteration's records (catalogues beyond the caches)
@@ -44,11 +48,13 @@ hipError_t launch_prepare_walkers(hipStream_t s, const double* params, int64_t n
 hipError_t launch_loglike(hipStream_t s, const LaunchShape& shape, const void* records, const Chunk* chunks,
                           int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers);
 
-// out[pset][w] = sum over the chunks of pset of partials[w / 8][chunk][w % 8]  (fixed order) [+ pset_const[pset]];
-// `partials` holds roundup64(n_walkers) x n_chunks doubles
-hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* pset_chunk_offsets,
-                         int64_t n_psets, int64_t n_chunks, int64_t max_chunks_per_pset, int64_t n_walkers,
+// out[pset][w] = sum over the slots of pset of partials[w / 8][slot][w % 8]  (fixed order) [+ pset_const[pset]];
+// `partials` holds roundup64(n_walkers) x n_slots doubles; slots = chunks unless the workgroups combine (partial_slots)
+hipError_t launch_reduce(hipStream_t s, const double* partials, const int64_t* pset_slot_offsets,
+                         int64_t n_psets, int64_t n_slots, int64_t max_slots_per_pset, int64_t n_walkers,
                          const double* pset_const, double* out);
+int64_t partial_slots(const LaunchShape& shape, int64_t n_chunks, int64_t n_walkers);
+constexpr int64_t kFusedReduceSlots = 256;   // up to here the reduction is one wave per walker group with one round of loads
 
 // per-star outputs for one parameter row: mode 0 membership probability, mode 1 mixture log-likelihood
 hipError_t launch_per_star(hipStream_t s, const LaunchShape& shape, const void* records, int64_t n,
@@ -77,6 +83,13 @@ struct StretchDevice {
     long long launch_index = 0;
 #endif
     int32_t force_general = 0;             // testing aid (option "device_chain" = 2): the general step kernel for any size
+    // fused reduction (launches whose partial sums are few, kFusedReduceSlots): the step kernel adds up the main kernel's
+    // partial sums itself instead of reading the sums a reduction kernel left in `ll` -- one kernel less per half step
+    int32_t fused = 0;
+    const double* partials = nullptr;      // [ceil64(W / 2) / 8][n_slots][8]
+    int64_t n_slots = 0;
+    const int64_t* slot_offsets = nullptr; // [n_bins + 1] slots of each ensemble (null for one ensemble: 0 .. n_slots)
+    const double* pset_const = nullptr;    // walker-independent sum per ensemble (fast fixed-background kernels), or null
     StatsScalars stats;                    // this device's share of the catalogue
     const int32_t* col_source = nullptr;   // [k]   as mcd::StretchDesc (mcd_stretch.h)
     const double* col_const = nullptr;     // [k]
@@ -106,6 +119,8 @@ hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t ac
 hipError_t launch_stretch_status(hipStream_t s, const int32_t* meta, double* out);
 // several ensembles need the step kernel that keeps an ensemble in LDS (<= 512 walkers, <= 12 columns, <= 32 KiB of positions)
 bool stretch_step_handles(const StretchDevice& d);
+// ... and only that kernel can add up the main kernel's partial sums itself (StretchDevice::fused)
+bool stretch_step_fuses(const StretchDevice& d);
 
 // background.SingleStars (mcd_kde.hip): slice plan and launch.  part_dmin / part_sum hold [n_slices][n] doubles.
 int kde_slices(int64_t n, int64_t m, int* slice_len);

@@ -21,6 +21,7 @@
 #include "mcd_guard.h"
 #include "mcd_math.h"
 #include "mcd_prep.h"
+#include "mcd_reduce.h"
 
 namespace mcd {
 
@@ -186,12 +187,41 @@ constexpr int kSmallPosBytes = 32 << 10;
 
 extern __shared__ double s_dynamic[];     // [W * P] positions | [W] log-probabilities | [W / 2] int32: the partner half
 
-template <int kMaxCols, bool kBinned>
-__global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchDevice d, int64_t acc_step, int acc_h,
-                                                                         int64_t prop_step, int prop_h,
-                                                                         const double* __restrict__ ll, double rerun_tag) {
+// kFused: the kernel runs with kFusedThreads threads; all of its waves first add up the main kernel's partial sums of this
+// ensemble (one wave per group of 8 walkers at a time, the reduction kernel's own code and order: mcd_reduce.h) into LDS,
+// then the waves beyond the first kStepBlock threads leave and the step proceeds as below with the sums read from LDS.
+constexpr int kFusedThreads = 1024;
+
+template <int kMaxCols, bool kBinned, bool kFused>
+__global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_step_small_kernel(
+    StretchDevice d, int64_t acc_step, int acc_h, int64_t prop_step, int prop_h, const double* __restrict__ ll,
+    double rerun_tag) {
     const int half = (int)(d.n_walkers / 2), W = 2 * half, P = d.n_dim, K = d.k;
     const int j = threadIdx.x;
+    __shared__ double s_ll[kFused ? kStepBlock : 1];
+    if constexpr (kFused) {
+        if (acc_step >= 0) {
+            const int64_t bb = kBinned ? blockIdx.x : 0;
+            const int64_t c0 = d.slot_offsets ? d.slot_offsets[bb] : 0, c1 = d.slot_offsets ? d.slot_offsets[bb + 1] : d.n_slots;
+            const double add = d.pset_const ? d.pset_const[bb] : 0.0;
+            const int q = j & 3, s = (j & 63) >> 2, n_groups = (half + kPartialGroup - 1) / kPartialGroup;
+            for (int g = j >> 6; g < n_groups; g += kFusedThreads / 64) {
+                const double2* __restrict__ col = reinterpret_cast<const double2*>(d.partials + (int64_t)g * d.n_slots * kPartialGroup) + q;
+                double ax, ay;
+                reduce_sublane_sum<8, 16, true>(col, c0, c1, s, ax, ay);      // (<= kFusedReduceSlots = 8 x 2 x 16 slots)
+                reduce_wave_combine(ax, ay);
+                if ((j & 63) < 4) {
+                    const int w = g * kPartialGroup + 2 * q;
+                    if (w < half) s_ll[w] = ax + add;
+                    if (w + 1 < half) s_ll[w + 1] = ay + add;
+                }
+            }
+        }
+        if (j >= kStepBlock) {
+            __syncthreads();          // hand the sums over, then leave (a finished wave no longer counts at later barriers)
+            return;
+        }
+    }
     // one workgroup per ensemble (radial bin): arrays carry the bin index in front of the walker index
     const int64_t B = kBinned ? d.n_bins : 1, b = kBinned ? blockIdx.x : 0;     // (one ensemble: no index arithmetic left)
     double* const pos_b = d.pos + b * W * P;
@@ -245,7 +275,7 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
         if (b == 0 && j == 0 && rerun_tag != 0.0) flag_word = ll[B * half];
         if (active) {
             ok_prev = ok_b[j] != 0;
-            ll_j = ll_b[j];
+            if constexpr (!kFused) ll_j = ll_b[j];
             w_acc = d.order[(acc_step * B + b) * W + (acc_h == 0 ? 0 : half) + j];
             thr_j = d.thr[((acc_step * 2 + acc_h) * B + b) * half + j];
 #pragma unroll
@@ -278,6 +308,7 @@ __global__ __launch_bounds__(kStepBlock) void stretch_step_small_kernel(StretchD
     }
     __syncthreads();
     MCD_STAMP(1);
+    if constexpr (kFused) { if (do_acc && active) ll_j = s_ll[j]; }
     // ---- accept / reject (walkers of one half step are distinct: no two threads touch the same row) ----
     if (do_acc) {
         if (b == 0 && j == 0 && rerun_tag != 0.0 && flag_word == rerun_tag) atomicOr(&d.meta[META_STATUS], CHAIN_RERUN);
@@ -439,6 +470,7 @@ bool small_step(const StretchDevice& d) {
 }  // namespace
 
 bool stretch_step_handles(const StretchDevice& d) { return d.n_bins == 1 || small_step(d); }
+bool stretch_step_fuses(const StretchDevice& d) { return small_step(d); }
 
 hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t acc_step, int acc_h, int64_t prop_step,
                                int prop_h, const double* ll, double rerun_tag) {
@@ -448,8 +480,15 @@ hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t ac
     const bool small = small_step(d);
     if (!small && d.n_bins != 1) return hipErrorInvalidValue;
 #define MCD_LAUNCH_SMALL(C, BINNED)                                                                                            \
-    hipLaunchKernelGGL((stretch_step_small_kernel<C, BINNED>), dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, s, d, acc_step, \
-                       acc_h, prop_step, prop_h, ll, rerun_tag)
+    do {                                                                                                                       \
+        if (d.fused)                                                                                                           \
+            hipLaunchKernelGGL((stretch_step_small_kernel<C, BINNED, true>), dim3((unsigned)d.n_bins), dim3(kFusedThreads),    \
+                               lds, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);                                  \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((stretch_step_small_kernel<C, BINNED, false>), dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, \
+                               s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);                                       \
+    } while (0)
+    if (d.fused && !small) return hipErrorInvalidValue;
     const bool binned = d.n_bins > 1;
     if (small && cols <= 4) { if (binned) MCD_LAUNCH_SMALL(4, true); else MCD_LAUNCH_SMALL(4, false); }
     else if (small && cols <= 8) { if (binned) MCD_LAUNCH_SMALL(8, true); else MCD_LAUNCH_SMALL(8, false); }

@@ -1,7 +1,7 @@
 """Scratch: one block of `mcd_stretch_move` on a C3-shaped catalogue, resident on the device and host-driven, wall clock
 per step; under `rocprofv3 --kernel-trace` the trace of the resident block shows the kernel durations and the gaps between
 them (tools/chain_trace_summary.py).
-    python tools/chain_probe.py [n_stars] [n_walkers] [n_steps]"""
+    python tools/chain_probe.py [n_stars] [n_walkers] [n_steps] [bgfixed|const]"""
 import os
 import sys
 import time
@@ -15,11 +15,15 @@ from mcmc_dynamics_amd.background import Gaussian
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+const = len(sys.argv) > 4 and sys.argv[4] == "const"
 cat = synthetic.make_catalog(n, config=3, background=True)
 centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
 lnbg = Gaussian(20.0, 40.0)(cat["v"], cat["verr"])
-g = native.Catalog(native.default_context(), cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST_BGFIXED,
-                   centre=centre, lnlike_bg=lnbg, pmember=cat["pmember"])
+if const:
+    g = native.Catalog(native.default_context(), cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST, centre=centre)
+else:
+    g = native.Catalog(native.default_context(), cat["ra"], cat["dec"], cat["v"], cat["verr"], model=native.MODEL_CONST_BGFIXED,
+                       centre=centre, lnlike_bg=lnbg, pmember=cat["pmember"])
 pos = synthetic.make_walkers(w, ["v_sys", "sigma_max", "v_maxx", "v_maxy"], cat["truth"], config=3)
 lnp = g.loglike(pos)
 plan = {"col_source": np.arange(4, dtype=np.int32), "col_const": np.zeros(4), "col_factor": np.ones(4),
@@ -36,8 +40,9 @@ def randoms(k):
     return order, zz, thr, rng.integers(0, half, size=(k, 2, half)).astype(np.int32)
 
 
-for device in (1, 0, 1):
+for device, fused in ((1, 1), (0, 1), (1, 0), (1, 1)):
     g.set_option("device_chain", device)
+    g.set_option("fused_reduce", fused)
     p, l = pos.copy(), lnp.copy()
     g.stretch_move(plan, p, l, *randoms(8))                      # warm: buffers, clocks
     best = 1e9
@@ -46,5 +51,5 @@ for device in (1, 0, 1):
         t0 = time.perf_counter()
         g.stretch_move(plan, p, l, *r)
         best = min(best, time.perf_counter() - t0)
-    print("device_chain {0}: {1:7.1f} us per step ({2:.0f} steps/s), info {3}".format(device, best / steps * 1e6, steps / best,
-                                                                                    g.stretch_info()), flush=True)
+    print("device_chain {0} fused_reduce {4}: {1:7.1f} us per step ({2:.0f} steps/s), info {3}".format(
+        device, best / steps * 1e6, steps / best, g.stretch_info(), fused), flush=True)
