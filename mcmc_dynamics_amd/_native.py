@@ -92,6 +92,11 @@ class StretchDesc(ctypes.Structure):
     ]
 
 
+# Environment switches the library or this binding reads (INTEGRATION.md lists them).  None is needed in production: they
+# select test stand-ins or tuning values, so load_library() says so on the package logger when one is set.
+TEST_SWITCHES = ("MCD_LIB_PATH", "MCD_RCCL_LIBRARY", "MCD_ALLOW_SHARED_DEVICE", "MCD_FORCE_RCCL", "MCD_TARGET_WAVES",
+                 "MCD_CHAIN_PART_BYTES", "MCD_COLLECTIVE_TIMEOUT_MS")
+
 _lib = None
 _live_catalogs = weakref.WeakSet()
 _live_contexts = weakref.WeakSet()
@@ -136,6 +141,11 @@ def load_library(path=None):
         fn.argtypes = argtypes
     if path is None:
         _lib = lib
+        active = ["{0}={1}".format(k, os.environ[k]) for k in TEST_SWITCHES if os.environ.get(k)]
+        if active:
+            import logging
+            logging.getLogger("mcmc_dynamics_amd").warning(
+                "test / tuning switches active (none is needed in production, see INTEGRATION.md): %s", ", ".join(active))
     return lib
 
 

@@ -153,10 +153,10 @@ extern "C" int emul_kde(int64_t m, const double* comp, int64_t n, const double* 
 extern "C" int64_t emul_plan_chunks(int64_t n_psets, const int64_t* bin_offsets, int64_t star_begin, int64_t n,
                                     int64_t n_walkers, int64_t target_waves, int tail_split, int64_t n_exc,
                                     const int64_t* exc, int64_t cap, int64_t* begin, int32_t* count, int32_t* pset,
-                                    uint8_t* general, int64_t* offsets, int64_t* info) {
+                                    uint8_t* general, int64_t* offsets, int64_t* info, int balance) {
     const std::vector<int64_t> offs(bin_offsets, bin_offsets + n_psets + 1);
     const std::vector<int64_t> ex(exc, exc + n_exc);
-    const ChunkPlan plan = plan_chunks(offs, star_begin, n, n_walkers, target_waves, tail_split, ex);
+    const ChunkPlan plan = plan_chunks(offs, star_begin, n, n_walkers, target_waves, tail_split, ex, 0, balance);
     const int64_t nc = (int64_t)plan.chunks.size();
     if (nc > cap) return -nc;
     for (int64_t i = 0; i < nc; ++i) {
@@ -166,6 +166,13 @@ extern "C" int64_t emul_plan_chunks(int64_t n_psets, const int64_t* bin_offsets,
     for (int64_t p = 0; p <= n_psets; ++p) offsets[p] = plan.offsets[p];
     info[0] = plan.max_chunks_per_pset; info[1] = plan.len; info[2] = plan.uniform_len;
     info[3] = plan.general.empty() ? 0 : 1; info[4] = main_grid(nc, n_walkers);
+    info[5] = plan.uniform_extra; info[6] = plan.balanced_m;
+    // the arithmetic form the main kernel computes instead of loading a descriptor must BE the table
+    if (plan.uniform_len > 0)
+        for (int64_t i = 0; i < nc; ++i) {
+            const Chunk u = uniform_chunk(i, plan.uniform_len, plan.uniform_extra, n, nc);
+            if (u.begin != plan.chunks[i].begin || u.count != plan.chunks[i].count) info[5] = -1;
+        }
     return nc;
 }
 

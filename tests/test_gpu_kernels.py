@@ -778,3 +778,78 @@ def test_record_prefetch_does_not_change_results(native, ctx, model, precision):
     with pytest.raises(native.NativeError, match="prefetch"):
         g2.set_option("prefetch", 2)
     g2.close()
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 4, 5, 6])
+def test_balanced_plans_and_combining_workgroups_against_the_oracle(native, ctx, model):
+    """Round 3: one round of equal waves (option "balance") with 4-, 8- and 16-wave workgroups (option "combine") for
+    1 .. 4 walker tiles and a ragged walker count, every model, fixed and free centre: each plan against the oracle (1e-12)
+    and within rounding of the multi-round schedule; bitwise repeatable; the plain kernels (fast_path 0) on the same plan."""
+    from oracle import lnprob_numpy as oracle
+    rng = np.random.default_rng(9300 + model)
+    for trial, (n, w) in enumerate([(20011, 256), (40000, 128), (30000, 64), (12345, 200), (9000, 320)]):
+        cat, sv = _realistic_case(rng, n=n)
+        cat["pmember"] = np.clip(cat["pmember"], 0.02, 0.98)          # (certain members / non-members: covered elsewhere)
+        free = bool(trial % 2) and model != 6
+        cols = [rng.normal(0, sv, w), sv * 10.0 ** rng.uniform(-0.5, 0.5, w)]
+        if model >= 3:
+            cols.append(10.0 ** rng.uniform(0.5, 2.0, w))
+        cols += [rng.normal(0, sv, w), rng.normal(0, sv, w)]
+        if model >= 3:
+            cols.append(10.0 ** rng.uniform(0.5, 2.0, w))
+        if free:
+            cols += [CENTRE_RA + rng.normal(0, 0.005, w), CENTRE_DEC + rng.normal(0, 0.005, w)]
+        if model in (2, 4):
+            cols += [rng.normal(0, sv, w), sv * 10.0 ** rng.uniform(-0.3, 0.6, w), 0.05 + 0.9 * rng.random(w)]
+        if model == 5:
+            cols.append(0.05 + 0.9 * rng.random(w))
+        params = np.stack(cols, axis=1)
+        lnbg = oracle.gaussian_background(cat["v"], cat["verr"], 0.0, 3 * sv)
+        kw = {}
+        if model in (1, 6):
+            kw = dict(lnlike_bg=lnbg, pmember=cat["pmember"])
+        elif model in (2, 4):
+            kw = dict(density=cat["density"])
+        elif model == 5:
+            kw = dict(lnlike_bg=lnbg, density=cat["density"])
+        g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model,
+                           centre=None if free else (CENTRE_RA, CENTRE_DEC), **kw)
+        g.set_option("balance", 0)
+        ref = g.loglike(params)
+        want = np.empty(min(w, 6))
+        for i, row in enumerate(params[:len(want)]):
+            rc, dc = (row[6 if model >= 3 else 4], row[7 if model >= 3 else 5]) if free else (CENTRE_RA, CENTRE_DEC)
+            if model == 0:
+                want[i] = oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], rc, dc)
+            elif model == 1:
+                want[i] = oracle.faithful_constant_lnlike(cat, row[0], row[1], row[2], row[3], rc, dc, lnbg, cat["pmember"])
+            elif model == 2:
+                want[i] = oracle.faithful_constant_gb_lnlike(cat, row[0], row[1], row[2], row[3], rc, dc, *row[-3:])
+            elif model == 3:
+                want[i] = oracle.faithful_model_lnlike(cat, *row[:6], rc, dc)
+            elif model == 4:
+                want[i] = oracle.faithful_model_gb_lnlike(cat, *row[:6], rc, dc, *row[-3:])
+            elif model == 5:
+                want[i] = oracle.faithful_model_cb_lnlike(cat, *row[:6], rc, dc, row[-1], lnbg)
+            else:
+                want[i] = oracle.faithful_model_lnlike(cat, *row[:6], rc, dc, lnbg, cat["pmember"])
+        assert np.max(np.abs(ref[:len(want)] - want) / np.maximum(np.abs(want), n)) < 1e-12
+        seen = set()
+        for balance in (-1, 1, 2, 3, 4, 8):
+            for combine in (0, 1, 8, 16):
+                for fast_path in (1, 0):
+                    g.set_option("fast_path", fast_path)
+                    g.set_option("combine", combine)
+                    g.set_option("balance", balance)
+                    got = g.loglike(params)
+                    again = g.loglike(params)
+                    info = g.launch_info()
+                    seen.add((info["chunks"], info["workgroups"]))
+                    assert np.array_equal(got, again), "not bitwise repeatable"
+                    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), n)) < 2e-13, (n, w, balance, combine, fast_path)
+        assert len(seen) >= (6 if trial == 0 else 1), seen           # the options really changed the launch shape
+        with pytest.raises(native.NativeError, match="balance"):
+            g.set_option("balance", 9)
+        with pytest.raises(native.NativeError, match="combine"):
+            g.set_option("combine", 3)
+        g.close()

@@ -49,8 +49,11 @@ def test_hot_kernels_use_scalar_record_loads_and_no_scratch():
     if not os.path.exists(asm_path):
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py")], capture_output=True, timeout=900, check=True)
     asm = open(asm_path).read()
-    for tag, vgpr_limit in (("ILi0ELb0EddLi1ELb0E", 64), ("ILi1ELb0EddLi2ELb0E", 64), ("ILi1ELb0EddLi2ELb1E", 64),
-                            ("ILi2ELb0EddLi2ELb1E", 128)):
+    for tag, vgpr_limit in (("ILi0ELb0EddLi1ELb0ELi4E", 64), ("ILi1ELb0EddLi2ELb0ELi4E", 64), ("ILi1ELb0EddLi2ELb1ELi4E", 64),
+                            ("ILi2ELb0EddLi2ELb1ELi4E", 128),
+                            # the combining workgroups of the balanced plans: same budgets (16 waves = 1024 threads: 128 VGPRs)
+                            ("ILi0ELb0EddLi1ELb0ELi8E", 64), ("ILi0ELb0EddLi1ELb0ELi16E", 64), ("ILi1ELb0EddLi2ELb0ELi16E", 64),
+                            ("ILi2ELb0EddLi2ELb0ELi8E", 128)):
         m = re.search(r"\n(_ZN3mcd12_GLOBAL__N_114loglike_kernel" + tag + r"[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end", asm, re.S)
         assert m, tag
         body = m.group(2)
@@ -60,3 +63,17 @@ def test_hot_kernels_use_scalar_record_loads_and_no_scratch():
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)) == 0
         # CONST and BGFIXED: 8 waves per SIMD; the Gaussian-background kernel trades occupancy for unrolling (4 waves)
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= vgpr_limit
+
+
+def test_committed_instruction_counts_belong_to_the_committed_sources():
+    """mcmc_dynamics_amd/csrc/isa_mix.json (what bench.py's roofline block prices the kernels with) carries a hash of the
+    kernel sources and of the extraction rules: it must be the tree's (the committed file was stale, every
+    build() left the tree dirty)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_mix
+    with open(os.path.join(ROOT, "mcmc_dynamics_amd", "csrc", "isa_mix.json")) as f:
+        committed = json.load(f)
+    assert committed["source_sha16"] == isa_mix.source_hash(), "run: python tools/isa_mix.py --json mcmc_dynamics_amd/csrc/isa_mix.json"
+    for key in ("const", "bgfixed", "bggauss", "profile", "const_f32", "const_f32acc64"):
+        assert key in committed["kernels"] and committed["kernels"][key]["valu_per_term"] > 0

@@ -23,7 +23,7 @@ from collections import Counter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mcmc_dynamics_amd", "csrc")
-SOURCES = ("mcd_kernels.hip", "mcd_math.h", "mcd_exp_table.h", "mcd_internal.h", "mcd_chunks.h")
+SOURCES = ("mcd_kernels.hip", "mcd_math.h", "mcd_exp_table.h", "mcd_internal.h", "mcd_chunks.h", "mcd_reduce.h")
 SLOT_NS = 2.33
 
 # (template tag, name, bench model key, stars per inner iteration, inner trips per outer iteration, selector)
@@ -46,6 +46,9 @@ KERNELS = [
     ("ILi4ELb0EddLi1E", "PROFILE_BGGAUSS fixed", "profile_bggauss", 4, 1, _sel(frexp=4)),
     ("ILi5ELb0EddLi1E", "PROFILE_BGDENS fixed", "profile_bgdens", 4, 1, _sel(frexp=4)),
     ("ILi0ELb0EffLi1E", "CONST fixed, f32", "const_f32", 16, 1, None),
+    ("ILi0ELb0EfdLi1E", "CONST fixed, f32 terms f64 sums", "const_f32acc64", 16, 1, None),
+    ("ILi1ELb0EffLi1E", "BGFIXED fixed, f32", "bgfixed_f32", 4, 1, None),
+    ("ILi1ELb0EfdLi1E", "BGFIXED fixed, f32 terms f64 sums", "bgfixed_f32acc64", 4, 1, None),
 ]
 
 
@@ -73,8 +76,9 @@ def analyse(out="/tmp/isa_mix"):
     # every fast kernel exists with and without the software prefetch of the next iteration's records (template
     # parameter PF, the last one of the mangled name): the main row is the instantiation without, `*_prefetch` fields and
     # a second table line give the one with
-    variants = [(tag + "Lb0EE", name, key, per, trips, selector, False) for tag, name, key, per, trips, selector in KERNELS]
-    variants += [(tag + "Lb1EE", name + ", prefetch", key, per, trips, selector, True) for tag, name, key, per, trips, selector in KERNELS]
+    # (the 4-wave instantiations: the combining 8- / 16-wave ones of the balanced plans run the same loops)
+    variants = [(tag + "Lb0ELi4EE", name, key, per, trips, selector, False) for tag, name, key, per, trips, selector in KERNELS]
+    variants += [(tag + "Lb1ELi4EE", name + ", prefetch", key, per, trips, selector, True) for tag, name, key, per, trips, selector in KERNELS]
     for tag, name, key, per, trips, selector, with_prefetch in variants:
         starts = [i for i, l in enumerate(asm) if l.startswith("_ZN3mcd12_GLOBAL__N_114loglike_kernel" + tag)]
         if not starts:
