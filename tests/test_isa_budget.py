@@ -49,18 +49,22 @@ def test_hot_kernels_use_scalar_record_loads_and_no_scratch():
     if not os.path.exists(asm_path):
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py")], capture_output=True, timeout=900, check=True)
     asm = open(asm_path).read()
-    for tag, vgpr_limit in (("ILi0ELb0EddLi1ELb0ELi4E", 64), ("ILi1ELb0EddLi2ELb0ELi4E", 64), ("ILi1ELb0EddLi2ELb1ELi4E", 64),
-                            ("ILi2ELb0EddLi2ELb1ELi4E", 128),
-                            # the combining workgroups of the balanced plans: same budgets (16 waves = 1024 threads: 128 VGPRs)
-                            ("ILi0ELb0EddLi1ELb0ELi8E", 64), ("ILi0ELb0EddLi1ELb0ELi16E", 64), ("ILi1ELb0EddLi2ELb0ELi16E", 64),
-                            ("ILi2ELb0EddLi2ELb0ELi8E", 128)):
+    for tag, vgpr_limit, scratch_limit in (
+            ("ILi0ELb0EddLi1ELb0ELi4E", 64, 0), ("ILi1ELb0EddLi2ELb0ELi4E", 64, 0), ("ILi1ELb0EddLi2ELb1ELi4E", 64, 0),
+            ("ILi2ELb0EddLi2ELb1ELi4E", 128, 0),
+            # the combining workgroups of the balanced plans: same budgets (16 waves = 1024 threads: 128 VGPRs).  The 8-wave
+            # kernel of the per-walker Gaussian background is held to the 4-wave kernel's 128 registers by its launch
+            # bound (left alone it takes 150 and loses a wave per SIMD: 53 - 58 us against 46.5 at 1e5 stars x 256 walkers)
+            # and pays with three to five spilled dwords outside the loop
+            ("ILi0ELb0EddLi1ELb0ELi8E", 64, 0), ("ILi0ELb0EddLi1ELb0ELi16E", 64, 0), ("ILi1ELb0EddLi2ELb0ELi16E", 64, 0),
+            ("ILi2ELb0EddLi2ELb0ELi8E", 128, 32)):
         m = re.search(r"\n(_ZN3mcd12_GLOBAL__N_114loglike_kernel" + tag + r"[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end", asm, re.S)
         assert m, tag
         body = m.group(2)
         assert "s_load_dwordx" in body                       # star records arrive through the scalar cache
-        assert "scratch_" not in body                        # no register spills in the hot kernels
+        assert scratch_limit or "scratch_" not in body       # no register spills in the hot kernels
         meta = re.search(r"\.amdhsa_kernel " + re.escape(m.group(1)) + r"\n(.*?)\.end_amdhsa_kernel", asm, re.S).group(1)
-        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)) == 0
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)) <= scratch_limit
         # CONST and BGFIXED: 8 waves per SIMD; the Gaussian-background kernel trades occupancy for unrolling (4 waves)
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= vgpr_limit
 
