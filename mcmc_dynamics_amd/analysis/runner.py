@@ -361,28 +361,59 @@ class Runner(object):
             i += 1
         return initials
 
-    # Which sampler drives ``__call__``: "auto" (default) -- the built-in stretch move whenever whole blocks of steps can
-    # run inside the library (box priors: ``mcd_stretch_move``, ensemble resident on the device; 86 % of the kernel rate
-    # against ~60 % through per-call Python), otherwise emcee if it can be imported, otherwise the built-in one driving
-    # ``lnprob_batch``; "emcee": the real ``emcee.EnsembleSampler`` as the reference uses it (runner.py:403; ImportError
-    # when missing); "builtin": never emcee.  Both samplers make emcee's default move and expose emcee 3's attributes.
+    # Which sampler drives ``__call__``.  The reference hands ``Runner.lnprob`` to ``emcee.EnsembleSampler`` and lets emcee
+    # drive the outer loop (runner.py:403, 416-419); so does this class whenever emcee can be imported:
+    #   "auto" (default)  emcee (gets ``lnprob_batch`` with ``vectorize=True``) if importable, otherwise the built-in sampler
+    #                     (``mcmc_dynamics_amd.sampler``: emcee's default move and attributes), with whole blocks of steps
+    #                     inside the library where that is possible (see "resident");
+    #   "emcee"           the real ``emcee.EnsembleSampler`` or ImportError;
+    #   "resident"        the built-in sampler with the ensemble resident on the device (``mcd_stretch_move``: 87 - 95 % of
+    #                     the kernel rate against ~60 % through one Python call per half step).  Needs box priors and the
+    #                     package's own posterior methods (``resident_ok``); ValueError otherwise;
+    #   "builtin"         never emcee: resident blocks where possible, else the built-in Python loop around ``lnprob_batch``.
+    # One INFO line per run names the driver.
     SAMPLER = "auto"
 
+    # methods that define the posterior: a sub-class that overrides one of them OUTSIDE this package (the reference's
+    # Runner is meant to be sub-classed: its ``lnlike`` is a placeholder, runner.py:219-238) changes what emcee would
+    # sample -- the library's block entry evaluates the built-in model and would silently ignore it
+    _POSTERIOR_METHODS = ("lnprob", "lnprob_batch", "lnlike", "lnlike_batch", "_lnlike_batch", "lnprior", "lnprior_batch",
+                          "fetch_parameter_values")
+
+    def resident_ok(self):
+        """(bool, reason): may whole blocks of steps run inside the library (``mcd_stretch_move``)?"""
+        if not self.NATIVE_STRETCH:
+            return False, "this class evaluates more than one un-binned catalogue per call (NATIVE_STRETCH is off)"
+        for name in self._POSTERIOR_METHODS:
+            fn = getattr(type(self), name, None)
+            module = getattr(fn, "__module__", None) or ""
+            if fn is not None and not module.startswith(__name__.rsplit(".", 2)[0] + "."):
+                return False, "{0}.{1} overrides the posterior outside the package".format(type(self).__name__, name)
+        if not self._plan().simple:
+            return False, "the priors are not plain boxes (expression priors / constrained parameters)"
+        return True, ""
+
     def _make_sampler(self, n_walkers, seed=None):
-        if self.SAMPLER not in ("auto", "emcee", "builtin"):
-            raise ValueError("Runner.SAMPLER must be 'auto', 'emcee' or 'builtin'")
-        resident = self._plan().simple and self.NATIVE_STRETCH
-        if self.SAMPLER == "emcee" or (self.SAMPLER == "auto" and not resident):
+        if self.SAMPLER not in ("auto", "emcee", "resident", "builtin"):
+            raise ValueError("Runner.SAMPLER must be 'auto', 'emcee', 'resident' or 'builtin'")
+        resident, why_not = self.resident_ok()
+        if self.SAMPLER == "resident" and not resident:
+            raise ValueError("Runner.SAMPLER = 'resident' is not possible here: " + why_not)
+        if self.SAMPLER in ("auto", "emcee"):
             try:
                 import emcee
                 sampler = emcee.EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True)
                 if seed is not None:
                     sampler._random.seed(seed)
+                logger.info("MCMC driver: emcee.EnsembleSampler around lnprob_batch (vectorize=True), as runner.py:403")
                 return sampler
             except ImportError:
                 if self.SAMPLER == "emcee":
                     raise
         from ..sampler import EnsembleSampler
+        logger.info("MCMC driver: built-in stretch move (emcee's default move), %s",
+                    "blocks of steps inside the library, ensemble resident on the device" if resident
+                    else "Python loop around lnprob_batch (" + why_not + ")")
         return EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True, seed=seed,
                                block_fn=self._stretch_block if resident else None)
 

@@ -423,10 +423,11 @@ def test_lnprob_batch_direct_route_equals_the_general_one(monkeypatch):
         assert fit.lnprob_batch(pos[:, 1:]).shape == (64,)
 
 
-def test_sampler_selection(monkeypatch):
-    """Runner.SAMPLER: box priors take the built-in stretch move with the library's block entry (whatever is importable),
-    expression priors take emcee when it is there, and "emcee" / "builtin" force either (runner.py:403 is what "emcee"
-    reproduces)."""
+def test_sampler_selection(monkeypatch, caplog):
+    """Runner.SAMPLER: "auto" hands the loop to emcee whenever it can be imported, with lnprob_batch and
+    vectorize=True (runner.py:403 is what it reproduces); without emcee the built-in sampler, with blocks of steps inside
+    the library for box priors; "resident" / "builtin" / "emcee" force one; one INFO line names the driver."""
+    import logging
     import sys
     import types
     g = load_golden("constant_fixed")
@@ -437,26 +438,89 @@ def test_sampler_selection(monkeypatch):
 
     class FakeEnsembleSampler(object):
         def __init__(self, nwalkers, ndim, fn, vectorize=False):
-            made.append((nwalkers, ndim, vectorize))
+            made.append((nwalkers, ndim, vectorize, fn))
             self._random = np.random.RandomState()
 
     monkeypatch.setitem(sys.modules, "emcee", types.SimpleNamespace(EnsembleSampler=FakeEnsembleSampler))
+    caplog.set_level(logging.INFO, logger="mcmc_dynamics_amd")
     s = cf._make_sampler(16, seed=3)
-    assert isinstance(s, EnsembleSampler) and s.block_fn is not None and not made          # resident blocks beat emcee
+    assert isinstance(s, FakeEnsembleSampler) and made[0][:3] == (16, 4, True) and made[0][3] == cf.lnprob_batch   # emcee drives
+    assert "emcee.EnsembleSampler" in caplog.text
+    cf.SAMPLER = "resident"
+    s = cf._make_sampler(16, seed=3)
+    assert isinstance(s, EnsembleSampler) and s.block_fn is not None and len(made) == 1
+    assert "resident on the device" in caplog.text
     cf.SAMPLER = "emcee"
-    assert isinstance(cf._make_sampler(16, seed=3), FakeEnsembleSampler) and made == [(16, 4, True)]
+    assert isinstance(cf._make_sampler(16, seed=3), FakeEnsembleSampler) and len(made) == 2
     cf.SAMPLER = "builtin"
-    assert isinstance(cf._make_sampler(16), EnsembleSampler) and len(made) == 1
-    cf.SAMPLER = "auto"
+    s = cf._make_sampler(16)
+    assert isinstance(s, EnsembleSampler) and s.block_fn is not None and len(made) == 2
     cf.parameters["sigma_max"].set(lnprior="-0.5 * (sigma_max - 10.0)**2")                  # not a box prior any more
-    assert not cf._plan().simple
-    assert isinstance(cf._make_sampler(16), FakeEnsembleSampler) and len(made) == 2
+    assert not cf._plan().simple and not cf.resident_ok()[0]
+    s = cf._make_sampler(16)
+    assert isinstance(s, EnsembleSampler) and s.block_fn is None                             # Python loop around lnprob_batch
+    cf.SAMPLER = "resident"
+    with pytest.raises(ValueError, match="not plain boxes"):
+        cf._make_sampler(16)
+    cf.SAMPLER = "auto"
+    assert isinstance(cf._make_sampler(16), FakeEnsembleSampler) and len(made) == 3
     monkeypatch.setitem(sys.modules, "emcee", None)                                          # import emcee -> ImportError
     s = cf._make_sampler(16)
     assert isinstance(s, EnsembleSampler) and s.block_fn is None
+    cf.parameters["sigma_max"].lnprior = None                                                # box priors again
+    s = cf._make_sampler(16)
+    assert isinstance(s, EnsembleSampler) and s.block_fn is not None                         # no emcee, box priors: resident
     cf.SAMPLER = "emcee"
     with pytest.raises(ImportError):
         cf._make_sampler(16)
     cf.SAMPLER = "nonsense"
     with pytest.raises(ValueError):
         cf._make_sampler(16)
+
+
+def test_a_subclass_that_changes_the_posterior_is_never_run_inside_the_library(monkeypatch):
+    """the library's block entry evaluates the built-in model; a Runner sub-class that overrides
+    lnprob_batch / lnlike_batch / lnprior ... outside the package (the reference's Runner is meant to be sub-classed) must
+    get the Python loop around ITS lnprob_batch, and the chain must reflect the override."""
+    import sys
+    monkeypatch.setitem(sys.modules, "emcee", None)
+    g = load_golden("constant_fixed")
+    data = DataReader({k: g[k] for k in ("ra", "dec", "v", "verr")})
+
+    class Tilted(ConstantFit):
+        calls = 0
+
+        def lnprob_batch(self, values):
+            Tilted.calls += 1
+            values = np.asarray(values, dtype=np.float64)
+            return -0.5 * np.sum((values - np.array([50.0, 3.0, -20.0, 20.0])) ** 2, axis=1)      # nothing like the data's posterior
+
+    class Penalised(ConstantFit):
+        def lnprior(self, values):
+            return super(Penalised, self).lnprior(values) - 1.0
+
+    for cls, method in ((Tilted, "lnprob_batch"), (Penalised, "lnprior")):
+        fit = cls(data)
+        fit.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+        fit.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+        ok, why = fit.resident_ok()
+        assert not ok and method in why, why
+        s = fit._make_sampler(16, seed=1)
+        assert isinstance(s, EnsembleSampler) and s.block_fn is None
+        fit.SAMPLER = "resident"
+        with pytest.raises(ValueError, match="overrides the posterior"):
+            fit._make_sampler(16)
+    plain = ConstantFit(data)
+    plain.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+    plain.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+    assert plain.resident_ok() == (True, "")
+    # the chain of the overriding class follows the override (no GPU involved: its lnprob_batch never touches the catalogue)
+    fit = Tilted(data)
+    fit.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+    fit.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+    rng = np.random.default_rng(5)
+    pos = np.array([50.0, 3.0, -20.0, 20.0]) + rng.normal(0, 1, size=(16, 4))
+    sampler = fit(n_walkers=16, n_steps=300, pos=pos, prefix=None)
+    assert Tilted.calls > 300
+    flat = sampler.get_chain(discard=100, flat=True)
+    assert np.all(np.abs(flat.mean(axis=0) - np.array([50.0, 3.0, -20.0, 20.0])) < 0.5)
