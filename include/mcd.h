@@ -119,6 +119,23 @@ int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out);
 int mcd_get_unique_id(void* out_id);
 int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id, mcd_ctx** out);
 
+/* ---- collective deadline (contexts with a communicator; nothing equivalent in the reference, whose only parallelism
+ * is the process pool of analysis/runner.py:398-403) -------------------------------------------------------------
+ * Every wait on a stream that carries an all-reduce (mcd_loglike_batch / _fetch, mcd_sync, mcd_stretch_move) polls
+ * instead of blocking: after `collective_timeout_ms` (option below; default 120000, 0 = wait for ever; the environment
+ * variable MCD_COLLECTIVE_TIMEOUT_MS sets the default of new contexts) the call returns MCD_ERR_RCCL with the stage in
+ * mcd_last_error(), and the context is marked FAILED: every later call on it (and on its catalogues) returns
+ * MCD_ERR_RCCL at once, and the destroy functions no longer synchronise the blocked streams (they would never
+ * return) -- the process is expected to report and exit non-zero.  There is no fallback inside the process.
+ *
+ * mcd_ctx_abort may be called from ANOTHER host thread while a call is waiting (e.g. by the host application's own
+ * control channel when a peer rank reports that it failed): the waiting call returns MCD_ERR_RCCL within a
+ * millisecond instead of running into the deadline.  This is how a rank that fails in the middle of a block of
+ * mcd_stretch_move keeps its peers from waiting inside the collective (mcmc_dynamics_amd/hostgroup.py: abort). */
+int mcd_ctx_set_option(mcd_ctx* ctx, const char* key, int64_t value);   /* "collective_timeout_ms" */
+int mcd_ctx_abort(mcd_ctx* ctx, const char* reason);                    /* thread-safe; reason may be NULL */
+int mcd_ctx_failed(const mcd_ctx* ctx);                                 /* 1 after a deadline / abort / mid-block error */
+
 int mcd_ctx_destroy(mcd_ctx* ctx);
 int mcd_ctx_n_devices(const mcd_ctx* ctx);
 /* What RCCL itself reports for the communicator of the context's first device: ncclCommCount, ncclCommUserRank and

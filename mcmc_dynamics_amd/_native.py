@@ -31,6 +31,9 @@ SYMBOLS = {
     "mcd_ctx_create_rank": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.POINTER(ctypes.c_void_p)]),
     "mcd_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_ctx_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
+    "mcd_ctx_abort": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "mcd_ctx_failed": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_ctx_n_devices": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_ctx_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                          ctypes.POINTER(ctypes.c_int)]),
@@ -197,6 +200,23 @@ class Context(object):
     @property
     def n_devices(self):
         return self.lib.mcd_ctx_n_devices(self.handle)
+
+    def set_option(self, key, value):
+        """Context options (include/mcd.h): ``collective_timeout_ms`` -- how long a wait on a stream that carries an
+        all-reduce may last before the call returns an error and the context is marked failed (0: for ever)."""
+        _check(self.lib, self.lib.mcd_ctx_set_option(self.handle, key.encode(), int(value)), "mcd_ctx_set_option")
+
+    def abort(self, reason=""):
+        """Make a call of ANOTHER thread that is waiting for a collective on this context return an error now (thread-safe;
+        what ``hostgroup.HostGroup`` calls when a peer rank reports a failure)."""
+        if getattr(self, "handle", None):
+            self.lib.mcd_ctx_abort(self.handle, str(reason).encode()[:400])
+
+    @property
+    def failed(self):
+        """True after a collective deadline, an abort, or an error in the middle of a resident block: every later call on
+        this context raises; the process is expected to exit non-zero (no fallback inside it)."""
+        return bool(getattr(self, "handle", None)) and bool(self.lib.mcd_ctx_failed(self.handle))
 
     def comm_info(self):
         """What RCCL reports for this context's communicator: {'size', 'rank', 'rccl_version'} (size 0: none)."""

@@ -499,8 +499,17 @@ class Runner(object):
         while sampler.iteration < n_steps:
             # runner.py:418-419.  One deliberate difference: the reference re-passes the caller's
             # `lnprob0` on every chunk although the positions have moved; it is used for the first chunk only.
-            result = sampler.run_mcmc(pos, n_out if n_out is not None else n_steps, log_prob0=lnprob0,
-                                      rstate0=state, progress=False)
+            try:
+                result = sampler.run_mcmc(pos, n_out if n_out is not None else n_steps, log_prob0=lnprob0,
+                                          rstate0=state, progress=False)
+            except BaseException as exc:
+                # several ranks: the peers are inside (or about to enter) an all-reduce this rank will not join any more.
+                # Tell them before the exception travels on (hostgroup.abort -> mcd_ctx_abort on their side): they leave
+                # their wait with an error at once instead of at the library's collective deadline.  Every rank ends with
+                # an exception; nothing is retried or re-routed inside the process.
+                if group is not None:
+                    group.abort("{0}: {1}".format(type(exc).__name__, exc))
+                raise
             pos, lnp, state = tuple(result)[:3]
             lnprob0 = None
             if n_out is not None:

@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>   // types and prototypes only: librccl.so is dlopen'ed on first multi-GPU use
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -186,6 +187,15 @@ struct mcd_ctx {
     int n_ranks = 1;
     bool multi_process = false;
     bool force_collective = false;     // MCD_FORCE_RCCL=1: run the all-reduce even on a 1-rank communicator (tests)
+    // collective deadline (include/mcd.h): waits on streams that carry an all-reduce poll, bounded by the deadline and
+    // by the abort flag another host thread may raise
+    int64_t collective_timeout_ms = 120000;
+    std::atomic<int> abort_flag{0};
+    std::atomic<int> failed{0};
+    std::mutex note_mutex;
+    std::string abort_reason;          // (guarded by note_mutex)
+    std::string failure;               // first failure: stage and cause
+    bool has_comm() const { return n_ranks > 1 || slots.size() > 1 || force_collective; }
 };
 
 struct mcd_catalog {
@@ -395,6 +405,63 @@ hipError_t wait_stream(hipStream_t s, int64_t spin_us) {
     return hipStreamSynchronize(s);
 }
 
+// The context failed (deadline, abort, an error in the middle of a block of launches other ranks are already committed
+// to): remember the first cause; every later call answers MCD_ERR_RCCL at once (ctx_usable).
+int ctx_fail(mcd_ctx* ctx, const std::string& what) {
+    {
+        std::lock_guard<std::mutex> lock(ctx->note_mutex);
+        if (!ctx->failed.load()) ctx->failure = what;
+        ctx->failed.store(1);
+    }
+    return fail(MCD_ERR_RCCL, what + " -- the context is unusable from here on: report and exit the process (no fallback "
+                                     "inside it; mcd.h: collective deadline)");
+}
+
+int ctx_usable(mcd_ctx* ctx) {
+    if (!ctx || !ctx->failed.load()) return MCD_OK;
+    std::lock_guard<std::mutex> lock(ctx->note_mutex);
+    return fail(MCD_ERR_RCCL, "this context failed earlier (" + ctx->failure + "): exit the process");
+}
+
+// Wait for a stream of a context.  Without a communicator: wait_stream.  With one, the stream may sit behind an
+// all-reduce whose peers never arrive: poll (spin first, then sleep between polls), give up at the deadline or when
+// another host thread raises the abort flag, and mark the context failed.  `stage` names the wait in the message.
+int wait_ctx_stream(mcd_ctx* ctx, hipStream_t s, int64_t spin_us, const char* stage) {
+    if (!ctx->has_comm() || ctx->collective_timeout_ms < 0) {
+        const hipError_t e = wait_stream(s, spin_us);
+        if (e != hipSuccess) return fail(MCD_ERR_HIP, std::string(stage) + ": " + hipGetErrorString(e));
+        return MCD_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t limit_us = ctx->collective_timeout_ms * 1000;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return MCD_OK;
+        if (q != hipErrorNotReady) return fail(MCD_ERR_HIP, std::string(stage) + ": " + hipGetErrorString(q));
+        if (ctx->abort_flag.load(std::memory_order_acquire)) {
+            std::string why;
+            { std::lock_guard<std::mutex> lock(ctx->note_mutex); why = ctx->abort_reason; }
+            return ctx_fail(ctx, std::string(stage) + ": aborted by the host while waiting for a collective (" +
+                                 (why.empty() ? "no reason given" : why) + ")");
+        }
+        const int64_t waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (limit_us > 0 && waited > limit_us) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "%s: no completion within collective_timeout_ms = %lld (rank %d of %d): a peer never "
+                                      "reached the all-reduce, or the fabric is down",
+                     stage, (long long)ctx->collective_timeout_ms, ctx->rank, ctx->n_ranks);
+            return ctx_fail(ctx, buf);
+        }
+        if (waited > spin_us) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
+
+#define MCD_WAIT(ctx, stream, spin, stage)                                                              \
+    do {                                                                                                \
+        const int w_rc_ = wait_ctx_stream((ctx), (stream), (spin), (stage));                            \
+        if (w_rc_ != MCD_OK) return w_rc_;                                                              \
+    } while (0)
+
 // Work buffers staged for walker count W (nullptr when the cache no longer holds them, e.g. after a failed upload)
 WorkSet* find_work(Shard& sh, int64_t W) {
     const auto it = sh.work.find(W);
@@ -433,6 +500,7 @@ bool wants_prefetch(const mcd_catalog* cat, const Shard& sh) {
 
 int stage_params_impl(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* params, bool zero_copy) {
     if (!cat || !params) return fail(MCD_ERR_INVALID, "null catalogue or params");
+    if (int rc = ctx_usable(cat->ctx)) return rc;
     if (n_walkers <= 0) return fail(MCD_ERR_INVALID, "n_walkers must be positive");
     if (k != cat->k) {
         char buf[128];
@@ -448,7 +516,7 @@ int stage_params_impl(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         // the pinned staging buffer may still be in flight from the previous call
-        MCD_HIP(wait_stream(slot.stream, cat->spin_us));
+        MCD_WAIT(cat->ctx, slot.stream, cat->spin_us, "mcd_params_upload (previous evaluation)");
         std::memcpy(w->h_params, params, (size_t)n_rows * k * sizeof(double));
         // Blocking single-device call: the walker-prep kernel reads the pinned host table over PCIe and the reduce
         // kernel writes the results straight into pinned host memory -- no copy-engine operations on the critical
@@ -482,6 +550,7 @@ int stage_params(mcd_catalog* cat, int64_t n_walkers, int32_t k, const double* p
 // pending on the communication stream, so that operations on one communicator never run concurrently).
 int enqueue(mcd_catalog* cat, bool pipelined) {
     if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
+    if (int rc = ctx_usable(cat->ctx)) return rc;
     if (cat->cur_walkers <= 0) return fail(MCD_ERR_INVALID, "no parameters staged (call mcd_params_upload first)");
     if (!all_staged(cat)) return fail(MCD_ERR_INVALID, "no parameters staged for this walker count (the last upload failed?)");
     const int64_t W = cat->cur_walkers;
@@ -603,11 +672,12 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
 
 int sync_all(mcd_catalog* cat) {
     if (!cat) return fail(MCD_ERR_INVALID, "null catalogue");
+    if (int rc = ctx_usable(cat->ctx)) return rc;
     for (Shard& sh : cat->shards) {
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
-        MCD_HIP(wait_stream(slot.stream, cat->spin_us));
-        MCD_HIP(wait_stream(slot.comm_stream, cat->spin_us));
+        MCD_WAIT(cat->ctx, slot.stream, cat->spin_us, "mcd_sync / mcd_loglike_fetch (compute stream)");
+        MCD_WAIT(cat->ctx, slot.comm_stream, cat->spin_us, "mcd_sync / mcd_loglike_fetch (communication stream)");
     }
     if (cat->timing && cat->timing_pending) {
         Shard& sh = cat->shards[0];
@@ -684,8 +754,10 @@ int fetch(mcd_catalog* cat, double* out) {
 
 // ------------------------------------------------------------------------------------------------
 // mcd_stretch_move with the ensemble resident on the device (mcd_stretch.hip).  Runs the whole block as one chain of
-// launches and waits once.  *done = false (and nothing of the caller's touched) when the block has to be run host-driven:
-// the configuration is not covered, or the device met something only the host loop handles (mcd::ChainStatus).
+// launches and waits once.  *done = false when the block has to be run host-driven: the configuration is not covered, or
+// the device met something only the host loop handles (mcd::ChainStatus).  `pos`, `lnp` and `accepted` are then
+// untouched; the chain rows of a large block (cut into parts) may already hold rows of the discarded attempt, which the
+// host-driven re-run overwrites (and which stay if that re-run fails).
 // user <-> pinned copies of tens of MB (a binned block: 40 MB of random numbers in, 70 MB of chain rows out) on four
 // threads: one core moves ~10 GB/s, the copies would otherwise cost as much as the block's device time
 void big_copy(void* dst, const void* src, size_t bytes) {
@@ -715,6 +787,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
                          double* lnprob_chain, int64_t* accepted, bool* done) {
     *done = false;
     mcd_ctx* ctx = cat->ctx;
+    if (int urc = ctx_usable(ctx)) return urc;
     const int64_t B = cat->n_psets;                    // ensembles: one per parameter set (mcd_stretch_move checked n_bins)
     if (!cat->device_chain || cat->shards.size() != 1 || cat->precision != MCD_F64 || n_steps < 1 || cat->timing || !d->fixed_ok)
         return MCD_OK;
@@ -735,8 +808,8 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     if (rc != MCD_OK) return rc;
     WorkSet& w = *wp;
     // nothing of an earlier call may still use the work buffers, the arena or the communicator
-    MCD_HIP(wait_stream(slot.stream, cat->spin_us));
-    MCD_HIP(wait_stream(slot.comm_stream, cat->spin_us));
+    MCD_WAIT(cat->ctx, slot.stream, cat->spin_us, "mcd_stretch_move (previous evaluation)");
+    MCD_WAIT(cat->ctx, slot.comm_stream, cat->spin_us, "mcd_stretch_move (previous collective)");
     w.comm_pending[0] = w.comm_pending[1] = false;
     w.staged = false;                     // the walker constants are about to be overwritten on the device
 
@@ -763,13 +836,22 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         if (a.h) (void)hipHostFree(a.h);
         a = ChainArena();
         const size_t want = total + total / 2;
-        // (a block too large for a device arena or for pinned host memory is no error: it runs host-driven, which needs
-        // neither; callers keep blocks of many ensembles short, analysis/binned.py)
-        if (hipMalloc((void**)&a.d, want) != hipSuccess) { (void)hipGetLastError(); a = ChainArena(); return MCD_OK; }
+        // (a block too large for a device arena or for pinned host memory is no error on ONE device: it runs host-driven,
+        // which needs neither; callers keep blocks of many ensembles short, analysis/binned.py.  In a multi-rank job the
+        // choice between the resident and the host-driven sequence must be the same on every rank -- their collectives
+        // differ in number and size -- so there a rank that cannot allocate reports the error instead)
+        const bool must_agree = ctx->n_ranks > 1 || ctx->force_collective;
+        if (hipMalloc((void**)&a.d, want) != hipSuccess) {
+            (void)hipGetLastError();
+            a = ChainArena();
+            if (must_agree) return fail(MCD_ERR_NOMEM, "mcd_stretch_move: no device memory for the resident block of this rank (use shorter blocks)");
+            return MCD_OK;
+        }
         if (hipHostMalloc((void**)&a.h, want, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(a.d);
             a = ChainArena();
+            if (must_agree) return fail(MCD_ERR_NOMEM, "mcd_stretch_move: no pinned host memory for the resident block of this rank (use shorter blocks)");
             return MCD_OK;
         }
         a.bytes = want;
@@ -903,6 +985,19 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         }
         return MCD_OK;
     };
+    // From the first launch on, the other ranks of a multi-rank job are committed to this block's sequence of
+    // collectives: an error on this rank in the middle of it (a failed launch, a refused ncclAllReduce) cannot be undone
+    // locally -- the peers would wait in an all-reduce this rank never enters.  The context is marked failed (the host
+    // tells the peers: hostgroup.abort -> mcd_ctx_abort on their side; their deadline bounds the wait otherwise).
+    struct MidBlockGuard {
+        mcd_ctx* ctx; bool armed; bool ok;
+        ~MidBlockGuard() {
+            if (armed && !ok && !ctx->failed.load()) {
+                const std::string cause = g_last_error;
+                (void)ctx_fail(ctx, "mcd_stretch_move: this rank failed in the middle of a resident block (" + cause + ")");
+            }
+        }
+    } mid_block{ctx, coll, false};
     bool rows_delivered = false;                               // chain rows already in the caller's arrays (parts)
     if (n_parts == 1) {
         MCD_HIP(hipMemcpyAsync(a.d, a.h, input_end, hipMemcpyHostToDevice, slot.stream));
@@ -913,7 +1008,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         MCD_HIP(hipMemcpyAsync(a.h, a.d, state_end, hipMemcpyDeviceToHost, slot.stream));
         if (total > o_chain)
             MCD_HIP(hipMemcpyAsync(a.h + o_chain, a.d + o_chain, total - o_chain, hipMemcpyDeviceToHost, slot.stream));
-        MCD_HIP(wait_stream(slot.stream, cat->spin_us));
+        MCD_WAIT(cat->ctx, slot.stream, cat->spin_us, "mcd_stretch_move (resident block)");
     } else {
         // events: in[k] the numbers of part k are on the device; rows[k] the chain rows of part k are final; out[k] they
         // are in pinned memory
@@ -935,7 +1030,8 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         };
         auto rows_to_caller = [&](int64_t k) -> int {          // wait for out[k], pinned -> the caller's arrays
             const size_t at = (size_t)part_begin(k) * BW, n = (size_t)(part_begin(k + 1) - part_begin(k)) * BW;
-            MCD_HIP(hipEventSynchronize(ev_out[k]));
+            // (the event is the last thing on the copy stream at this point: wait for the stream, with the context's deadline)
+            MCD_WAIT(cat->ctx, slot.comm_stream, cat->spin_us, "mcd_stretch_move (chain rows of a part)");
             if (chain) big_copy(chain + at * P, a.h + o_chain + at * P * 8, n * P * 8);
             if (lnprob_chain) big_copy(lnprob_chain + at, a.h + o_lnpc + at * 8, n * 8);
             return MCD_OK;
@@ -968,8 +1064,8 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         if (rc != MCD_OK) return rc;
         rc = rows_to_caller(n_parts - 1);
         if (rc != MCD_OK) return rc;
-        MCD_HIP(wait_stream(slot.stream, cat->spin_us));
-        MCD_HIP(wait_stream(slot.comm_stream, cat->spin_us));
+        MCD_WAIT(cat->ctx, slot.stream, cat->spin_us, "mcd_stretch_move (resident block, last part)");
+        MCD_WAIT(cat->ctx, slot.comm_stream, cat->spin_us, "mcd_stretch_move (resident block, chain rows)");
         rows_delivered = true;   // (a discarded block leaves garbage there: the host-driven re-run overwrites every row)
     }
 #ifdef MCD_CHAIN_STAMPS
@@ -992,6 +1088,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     }
 #endif
 
+    mid_block.ok = true;
     w.fast = level;
     cat->cur_walkers = half;
     cat->last_chunks = w.n_chunks;
@@ -1062,6 +1159,7 @@ int mcd_ctx_create(int n_dev, const int* dev_ids, mcd_ctx** out) {
     std::unique_ptr<mcd_ctx, int (*)(mcd_ctx*)> ctx(new (std::nothrow) mcd_ctx(), &mcd_ctx_destroy);   // streams / communicators released on every error path
     if (!ctx) return fail(MCD_ERR_INVALID, "out of memory");
     ctx->slots.resize(n_dev);
+    if (const char* t = std::getenv("MCD_COLLECTIVE_TIMEOUT_MS")) ctx->collective_timeout_ms = std::max<long long>(0, std::atoll(t));
     std::vector<int> ids(n_dev);
     for (int i = 0; i < n_dev; ++i) {
         ids[i] = dev_ids ? dev_ids[i] : i;
@@ -1110,6 +1208,7 @@ int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id
     std::unique_ptr<mcd_ctx, int (*)(mcd_ctx*)> ctx(new (std::nothrow) mcd_ctx(), &mcd_ctx_destroy);   // streams / communicators released on every error path
     if (!ctx) return fail(MCD_ERR_INVALID, "out of memory");
     ctx->slots.resize(1);
+    if (const char* t = std::getenv("MCD_COLLECTIVE_TIMEOUT_MS")) ctx->collective_timeout_ms = std::max<long long>(0, std::atoll(t));
     int rc = make_slot(device, &ctx->slots[0]);
     if (rc != MCD_OK) return rc;
     const char* force = std::getenv("MCD_FORCE_RCCL");
@@ -1132,6 +1231,9 @@ int mcd_ctx_create_rank(int device, int rank, int n_ranks, const void* unique_id
 
 int mcd_ctx_destroy(mcd_ctx* ctx) {
     if (!ctx) return MCD_OK;
+    // a failed context has streams blocked behind a collective that will never finish: destroying them or the
+    // communicator would block this thread as well.  The handles are abandoned; the process is about to exit.
+    if (ctx->failed.load()) { delete ctx; return MCD_OK; }
     for (DeviceSlot& s : ctx->slots) {
         (void)hipSetDevice(s.device);
         if (s.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s.comm);
@@ -1143,6 +1245,32 @@ int mcd_ctx_destroy(mcd_ctx* ctx) {
 }
 
 int mcd_ctx_n_devices(const mcd_ctx* ctx) { return ctx ? (int)ctx->slots.size() : 0; }
+
+int mcd_ctx_set_option(mcd_ctx* ctx, const char* key, int64_t value) {
+    try {
+    if (!ctx || !key) return fail(MCD_ERR_INVALID, "mcd_ctx_set_option: null argument");
+    if (!std::strcmp(key, "collective_timeout_ms")) {
+        if (value < 0) return fail(MCD_ERR_INVALID, "collective_timeout_ms must be >= 0 (0: wait for ever)");
+        ctx->collective_timeout_ms = value;
+        return MCD_OK;
+    }
+    return fail(MCD_ERR_INVALID, std::string("unknown context option: ") + key);
+    } catch (...) { return on_exception("mcd_ctx_set_option"); }
+}
+
+int mcd_ctx_abort(mcd_ctx* ctx, const char* reason) {
+    try {
+    if (!ctx) return fail(MCD_ERR_INVALID, "mcd_ctx_abort: null context");
+    {
+        std::lock_guard<std::mutex> lock(ctx->note_mutex);
+        if (ctx->abort_reason.empty() && reason) ctx->abort_reason = reason;
+    }
+    ctx->abort_flag.store(1, std::memory_order_release);
+    return MCD_OK;
+    } catch (...) { return on_exception("mcd_ctx_abort"); }
+}
+
+int mcd_ctx_failed(const mcd_ctx* ctx) { return ctx && ctx->failed.load() ? 1 : 0; }
 
 int mcd_ctx_comm_info(const mcd_ctx* ctx, int* comm_size, int* comm_rank, int* rccl_version) {
     try {
@@ -1184,6 +1312,7 @@ int mcd_catalog_create(mcd_ctx* ctx, const mcd_catalog_desc* d, mcd_catalog** ou
 }
 
 static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::unique_ptr<mcd_catalog>& cat) {
+    if (int urc = ctx_usable(ctx)) return urc;
     if (d->n_stars < 0) return fail(MCD_ERR_INVALID, "negative n_stars");
     if (d->model < 0 || d->model >= mcd::kNumModels) return fail(MCD_ERR_INVALID, "unknown model");
     const int bgk = mcd::bg_kind(d->model);
@@ -1273,6 +1402,7 @@ static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::uni
 
 int mcd_catalog_destroy(mcd_catalog* cat) {
     if (!cat) return MCD_OK;
+    if (cat->ctx && cat->ctx->failed.load()) { delete cat; return MCD_OK; }      // (see mcd_ctx_destroy: nothing may be waited for)
     for (Shard& sh : cat->shards) {
         (void)hipSetDevice(cat->ctx->slots[sh.slot].device);
         (void)hipStreamSynchronize(cat->ctx->slots[sh.slot].stream);

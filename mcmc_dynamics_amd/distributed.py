@@ -91,4 +91,7 @@ def rank_context(group=None, device=None):
     uid = group.bcast_bytes(_native.Context.unique_id() if rank == 0 else None, src=0)
     ctx = _native.Context(rank=rank, n_ranks=world, unique_id=uid, device=dev)
     ctx.host_group = group
+    # a peer that fails says so over the group's abort channel: a call of this rank that is waiting inside the device
+    # all-reduce then returns an error at once instead of running into the library's collective deadline
+    group.on_abort(ctx.abort)
     return ctx

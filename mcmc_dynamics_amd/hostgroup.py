@@ -18,12 +18,21 @@ Rendezvous (how the other ranks find rank 0's listening socket), from the launch
   port on all interfaces, the others connect to ``MASTER_ADDR:<port>``.
 
 Collectives are deterministic: the hub combines contributions in rank order.
+
+Abort channel (round 3).  The collectives above are request / response on one socket per rank and a rank that sits in a
+library call cannot answer them.  So that a rank which FAILS (an exception inside a block of ``mcd_stretch_move``, a refused
+launch) can tell its peers -- who would otherwise wait inside the device all-reduce until the library's collective deadline
+-- every rank keeps a second connection to the hub with a daemon thread reading it: ``abort(reason)`` sends one message,
+the hub relays it to everybody, and every rank's callbacks (``on_abort``: ``Context.abort``, i.e. ``mcd_ctx_abort``) run on
+the listener thread within milliseconds.  After an abort every collective of the group raises ``HostGroupError``.
 """
 import json
 import os
+import select
 import socket
 import struct
 import tempfile
+import threading
 import time
 import zlib
 
@@ -81,10 +90,25 @@ class HostGroup(object):
         self._listener = None
         self._file = None
         self._seq = 0
+        self._ctl_peers = {}       # hub: rank -> control socket
+        self._ctl_hub = None       # others: control socket to rank 0
+        self._ctl_thread = None
+        self._ctl_lock = threading.Lock()
+        self._abort_callbacks = []
+        self.aborted = None        # reason (str) once any rank has called abort()
+        self._closing = False
         if not 0 <= self.rank < self.world:
             raise HostGroupError("rank {0} outside world of size {1}".format(rank, world))
         if self.world > 1:
             self._connect(os.environ if env is None else env)
+            self._ctl_thread = threading.Thread(target=self._control_loop, name="mcd-hostgroup-control", daemon=True)
+            self._ctl_thread.start()
+            # a normal interpreter exit says goodbye on the control connection; a process that dies does not, and its
+            # peers take that as a failure of the job (see _control_loop)
+            import atexit
+            import weakref
+            ref = weakref.ref(self)
+            atexit.register(lambda: ref() is not None and ref().close())
 
     @classmethod
     def from_env(cls, timeout=300.0):
@@ -110,7 +134,7 @@ class HostGroup(object):
                 with open(tmp, "w") as f:
                     json.dump({"port": srv.getsockname()[1], "pid": os.getpid(), "token": token, "world": self.world}, f)
                 os.replace(tmp, self._file)                       # atomic: readers see the old or the new file
-            while len(self._peers) < self.world - 1:
+            while len(self._peers) < self.world - 1 or len(self._ctl_peers) < self.world - 1:
                 srv.settimeout(max(0.1, deadline - time.monotonic()))
                 try:
                     conn, _ = srv.accept()
@@ -125,12 +149,15 @@ class HostGroup(object):
                     conn.close()
                     continue
                 r = hello.get("rank")
+                table = self._ctl_peers if hello.get("control") else self._peers
                 if hello.get("token") != token or hello.get("world") != self.world or not isinstance(r, int) \
-                        or not 0 < r < self.world or r in self._peers:
+                        or not 0 < r < self.world or r in table:
                     conn.close()                                   # a stray or stale client: ignore it
                     continue
                 _send(conn, {"ok": True})
-                self._peers[r] = conn
+                if hello.get("control"):
+                    conn.settimeout(None)
+                table[r] = conn
         else:
             addr = env.get("MASTER_ADDR", "127.0.0.1") if port else "127.0.0.1"
             last = "no rendezvous file yet"
@@ -147,23 +174,118 @@ class HostGroup(object):
                         if info.get("token") != token or info.get("world") != self.world:
                             raise ValueError("rendezvous file belongs to another job")
                         target = int(info["port"])
-                    s = socket.create_connection((addr, target), timeout=5.0)
-                    s.settimeout(self.timeout)
-                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    _send(s, {"rank": self.rank, "world": self.world, "token": token})
-                    ack, _ = _recv(s)
-                    if not ack.get("ok"):
-                        raise ValueError("hub refused the connection")
-                    self._hub = s
+                    socks = []
+                    for control in (False, True):
+                        s = socket.create_connection((addr, target), timeout=5.0)
+                        socks.append(s)
+                        s.settimeout(self.timeout)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        _send(s, {"rank": self.rank, "world": self.world, "token": token, "control": control})
+                        ack, _ = _recv(s)
+                        if not ack.get("ok"):
+                            for x in socks:
+                                x.close()
+                            raise ValueError("hub refused the connection")
+                    self._hub, self._ctl_hub = socks
+                    self._ctl_hub.settimeout(None)
                     return
                 except (OSError, ValueError, KeyError, HostGroupError) as exc:   # stale file, hub not up yet: retry
                     last = repr(exc)
                     time.sleep(0.05)
 
+    # ------------------------------------------------------------------ abort channel
+    def on_abort(self, callback):
+        """``callback(reason)`` runs on the listener thread of THIS rank when any rank calls ``abort`` (its own included)."""
+        with self._ctl_lock:
+            self._abort_callbacks.append(callback)
+            reason = self.aborted
+        if reason is not None:
+            callback(reason)
+
+    def abort(self, reason):
+        """Tell every rank of the group that this rank failed: their ``on_abort`` callbacks run (``mcd_ctx_abort``: a peer
+        waiting inside the device all-reduce returns an error at once) and every later collective of the group raises.
+        Never raises itself: it is called from exception handlers."""
+        reason = "rank {0}: {1}".format(self.rank, str(reason)[:500])
+        self._deliver_abort(reason)
+        try:
+            if self.world > 1:
+                if self.rank == 0:
+                    self._relay_abort(reason, skip=None)
+                elif self._ctl_hub is not None:
+                    _send(self._ctl_hub, {"kind": "abort", "reason": reason})
+        except (OSError, HostGroupError):
+            pass
+
+    def _deliver_abort(self, reason):
+        with self._ctl_lock:
+            if self.aborted is not None:
+                return
+            self.aborted = reason
+            callbacks = list(self._abort_callbacks)
+        for cb in callbacks:
+            try:
+                cb(reason)
+            except Exception:
+                pass
+
+    def _relay_abort(self, reason, skip):
+        for r, sock in list(self._ctl_peers.items()):
+            if r == skip:
+                continue
+            try:
+                _send(sock, {"kind": "abort", "reason": reason})
+            except (OSError, HostGroupError):
+                pass
+
+    def _control_loop(self):
+        """Daemon thread: wait for abort messages on the control connection(s)."""
+        try:
+            while not self._closing:
+                socks = list(self._ctl_peers.values()) if self.rank == 0 else [self._ctl_hub]
+                socks = [s for s in socks if s is not None]
+                if not socks:
+                    return
+                ready, _, _ = select.select(socks, [], [], 0.2)
+                for sock in ready:
+                    try:
+                        header, _ = _recv(sock)
+                    except (HostGroupError, OSError, ValueError, struct.error):
+                        # the peer is gone.  Without a goodbye (close() sends one) it died: that is a failure of the job
+                        if not self._closing:
+                            who = next((r for r, s in self._ctl_peers.items() if s is sock), 0)
+                            reason = "rank {0} closed its control connection without a goodbye (process died?)".format(who)
+                            self._deliver_abort(reason)
+                            if self.rank == 0:
+                                self._relay_abort(reason, skip=who)
+                        if self.rank == 0:
+                            for r, s in list(self._ctl_peers.items()):
+                                if s is sock:
+                                    del self._ctl_peers[r]
+                        else:
+                            return
+                        continue
+                    if header.get("kind") == "abort":
+                        self._deliver_abort(header.get("reason", "unknown"))
+                        if self.rank == 0:
+                            who = next((r for r, s in self._ctl_peers.items() if s is sock), None)
+                            self._relay_abort(header.get("reason", "unknown"), skip=who)
+                    elif header.get("kind") == "bye":
+                        if self.rank == 0:
+                            for r, s in list(self._ctl_peers.items()):
+                                if s is sock:
+                                    del self._ctl_peers[r]
+                        else:
+                            return
+        except Exception:
+            return
+
     # ------------------------------------------------------------------ collectives
     def _exchange(self, kind, header, payload, combine):
         """Every rank contributes (header, payload); the hub calls ``combine(list of (header, payload) in rank order)``
         -> (header, payload) and sends the result to everybody."""
+        if self.aborted is not None:
+            raise HostGroupError("the job was aborted: " + self.aborted)
         self._seq += 1
         header = dict(header, kind=kind, seq=self._seq)
         if self.world == 1:
@@ -256,6 +378,18 @@ class HostGroup(object):
         return int(both[0]) == -int(both[1])
 
     def close(self):
+        self._closing = True
+        for s in list(self._ctl_peers.values()) + [self._ctl_hub]:
+            if s is not None:
+                try:
+                    _send(s, {"kind": "bye"})
+                except (OSError, HostGroupError):
+                    pass
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._ctl_peers, self._ctl_hub = {}, None
         for s in list(self._peers.values()) + [self._hub, self._listener]:
             if s is not None:
                 try:

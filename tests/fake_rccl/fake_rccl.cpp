@@ -3,8 +3,17 @@
 // catalogue's streams) with REAL shards and REAL kernels.  RCCL itself refuses two ranks on one device ("invalid usage"),
 // so on the single-GPU development box the code that runs with star_begin > 0, per-shard background sums, re-run signals
 // crossing ranks etc. would otherwise never execute on a device.  Selected with MCD_RCCL_LIBRARY=<this .so>; never loaded
-// by the product otherwise.  It is NOT a performance model: every all-reduce synchronises its stream, stages through host
-// memory (POSIX shared memory between processes) and sums in rank order.
+// by the product otherwise.  It is NOT a performance model: results are staged through host memory (POSIX shared memory
+// between processes) and summed in rank order.
+//
+// Between PROCESSES the all-reduce is asynchronous like the real one (a stand-in that synchronises its stream
+// hides missing waits between the library's two streams and reuse of a buffer a collective still reads): the call only
+// enqueues, in stream order, a device-to-host copy into pinned memory, a host function (hipLaunchHostFunc) that meets the
+// other ranks in shared memory and sums, and the copy back.  The stream stays blocked while a peer is missing -- exactly
+// how a real all-reduce behaves when a rank never arrives, which is what the library's collective deadline
+// (include/mcd.h) is tested against: FAKE_RCCL_HANG_AT_CALL=k makes this rank's k-th all-reduce sit for
+// FAKE_RCCL_HANG_MS (default 30000) before it proceeds.  The single-process clique (ncclGroupStart/End over several
+// local devices) keeps the synchronous form.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -14,7 +23,9 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <random>
 #include <string>
@@ -48,6 +59,9 @@ struct ncclComm {
     Shared* shm = nullptr;                       // multi-process
     std::string shm_name;
     LocalGroup* local = nullptr;                 // single-process clique
+    double* h_in = nullptr;                      // pinned staging of the asynchronous form (one all-reduce at a time per
+    double* h_out = nullptr;                     // communicator, as with the real library)
+    long calls = 0;
 };
 
 namespace {
@@ -67,16 +81,45 @@ bool barrier(Shared* s, int n) {
     return true;
 }
 
+struct PendingReduce { ncclComm* c; size_t count; long hang_ms; };
+
+// runs on a runtime thread, in stream order, between the two copies: no HIP calls in here
+void host_reduce(void* arg) {
+    PendingReduce* p = static_cast<PendingReduce*>(arg);
+    ncclComm* c = p->c;
+    const size_t count = p->count;
+    for (long waited = 0; waited < p->hang_ms; waited += 10) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    std::memcpy(c->shm->data[c->rank], c->h_in, count * sizeof(double));
+    bool ok = barrier(c->shm, c->n_ranks);
+    for (size_t i = 0; i < count; ++i) c->h_out[i] = 0.0;
+    for (int r = 0; ok && r < c->n_ranks; ++r)
+        for (size_t i = 0; i < count; ++i) c->h_out[i] += c->shm->data[r][i];  // rank order: the same bits on every rank
+    ok = ok && barrier(c->shm, c->n_ranks);                                    // nobody overwrites a slot still being read
+    if (!ok)
+        for (size_t i = 0; i < count; ++i) c->h_out[i] = std::numeric_limits<double>::quiet_NaN();   // a peer never came
+    delete p;
+}
+
 ncclResult_t reduce_processes(ncclComm_t c, const void* send, void* recv, size_t count, hipStream_t stream) {
     if (count > kMaxCount) return ncclInvalidArgument;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipMemcpy(c->shm->data[c->rank], send, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-    if (!barrier(c->shm, c->n_ranks)) return ncclSystemError;
-    std::vector<double> sum(count, 0.0);
-    for (int r = 0; r < c->n_ranks; ++r)
-        for (size_t i = 0; i < count; ++i) sum[i] += c->shm->data[r][i];        // rank order: the same bits on every rank
-    if (!barrier(c->shm, c->n_ranks)) return ncclSystemError;                 // nobody overwrites a slot still being read
-    if (hipMemcpy(recv, sum.data(), count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipSetDevice(c->device) != hipSuccess) return ncclUnhandledCudaError;
+    if (!c->h_in) {
+        if (hipHostMalloc((void**)&c->h_in, kMaxCount * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&c->h_out, kMaxCount * sizeof(double), hipHostMallocDefault) != hipSuccess)
+            return ncclUnhandledCudaError;
+    }
+    ++c->calls;
+    long hang_ms = 0;
+    if (const char* at = std::getenv("FAKE_RCCL_HANG_AT_CALL"))
+        if (std::atol(at) == c->calls) {
+            const char* ms = std::getenv("FAKE_RCCL_HANG_MS");
+            hang_ms = ms ? std::atol(ms) : 30000;
+        }
+    PendingReduce* p = new PendingReduce{c, count, hang_ms};
+    if (hipMemcpyAsync(c->h_in, send, count * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipLaunchHostFunc(stream, host_reduce, p) != hipSuccess ||
+        hipMemcpyAsync(recv, c->h_out, count * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess)
+        return ncclUnhandledCudaError;
     return ncclSuccess;
 }
 
@@ -154,6 +197,8 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
         munmap(c->shm, sizeof(Shared));
         if (c->rank == 0) shm_unlink(c->shm_name.c_str());
     }
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->local && c->rank == 0) delete c->local;
     delete c;
     return ncclSuccess;

@@ -4,6 +4,10 @@ real streams; only the collective itself is host-staged.
 
     fake_rccl_worker.py single N         one process, N "devices" (all device 0): mcd_ctx_create(n_dev = N)
     fake_rccl_worker.py rank             one process per rank (RANK / WORLD_SIZE from the launcher): mcd_ctx_create_rank
+    fake_rccl_worker.py deadline KIND    two ranks, one of which never completes a collective (KIND: hang -- the stand-in's
+                                         all-reduce sits; raise -- rank 1 raises inside a block of Runner.__call__; die --
+                                         rank 1's process dies): rank 0 must get the error within the collective deadline
+                                         (hang) or at once (raise / die: the host group's abort channel), never wait for ever
 """
 import os
 import sys
@@ -193,8 +197,87 @@ def rank_mode():
     group.close()
 
 
+def deadline(kind):
+    """VERDICT r2 item 2.  Every rank ends with exit status 3 (error seen, reported, left) or 9 (the rank that dies); a
+    status 0 or a hang is the failure.  Prints DEADLINE_OK <rank> <kind> <seconds from the fault to the error>."""
+    import time
+    from mcmc_dynamics_amd import DataReader
+    from mcmc_dynamics_amd.analysis import ConstantFit
+    ctx = distributed.rank_context(device=0)
+    rank, world, group = ctx.rank, ctx.n_ranks, ctx.host_group
+    timeout_ms = 2500
+    ctx.set_option("collective_timeout_ms", timeout_ms)
+    cb = catalog(20000, 3, True)
+    cols = {k: cb[k] for k in ("ra", "dec", "v", "verr", "pmember")}
+    fit = ConstantFit(DataReader(distributed.shard_columns(cols, rank, world)), background=Gaussian(20.0, 40.0), context=ctx)
+    fit.parameters["ra_center"].set(value=CENTRE[0], fixed=True)
+    fit.parameters["dec_center"].set(value=CENTRE[1], fixed=True)
+    pos = synthetic.make_walkers(32, NAMES4, cb["truth"], config=3)
+    lp = fit.lnprob_batch(pos)                                                # a healthy collective first
+    assert group.same_everywhere(lp) and not ctx.failed
+    group.barrier()
+    t0 = time.monotonic()
+    err = None
+    try:
+        if kind == "hang":
+            # from here on rank 1's all-reduces sit (FAKE_RCCL_HANG_AT_CALL was set for rank 1 before the library loaded):
+            # blocking calls on both ranks run into the deadline -- rank 0 waits for a peer that never arrives
+            for _ in range(6):
+                fit.lnprob_batch(pos)
+        else:
+            calls = {"n": 0}
+            inner = fit._stretch_block
+
+            def flaky(*args):
+                calls["n"] += 1
+                if rank == 1 and calls["n"] == 2:
+                    if kind == "die":
+                        sys.stdout.flush()
+                        os._exit(9)
+                    raise RuntimeError("injected failure inside block 2 on rank 1")
+                return inner(*args)
+            fit._stretch_block = flaky
+            fit.SAMPLER = "builtin"
+            import mcmc_dynamics_amd.sampler as sampler_mod
+            orig_init = sampler_mod.EnsembleSampler.__init__
+
+            def short_blocks(self, *a, **k):
+                orig_init(self, *a, **k)
+                self.block_steps = 8
+            sampler_mod.EnsembleSampler.__init__ = short_blocks
+            fit(n_walkers=32, n_steps=64, pos=pos, prefix=None)
+    except BaseException as exc:                                               # NativeError, RuntimeError, HostGroupError
+        err = exc
+    elapsed = time.monotonic() - t0
+    assert err is not None, "rank {0}: no error although a peer never completed its collective".format(rank)
+    text = "{0}: {1}".format(type(err).__name__, err)
+    if kind == "hang":
+        assert isinstance(err, native.NativeError) and "collective_timeout_ms" in text, text
+        assert timeout_ms / 1000.0 * 0.8 < elapsed < timeout_ms / 1000.0 + 6.0, elapsed
+    elif rank == 0:
+        assert isinstance(err, native.NativeError) and "aborted by the host" in text, text
+        assert ("injected failure" in text) if kind == "raise" else ("closed its control connection" in text), text
+        assert elapsed < 8.0, elapsed                                          # at once, not at the deadline of a healthy job
+    else:
+        assert "injected failure" in text, text
+    if rank == 0 or kind == "hang":
+        assert ctx.failed
+        try:
+            fit.lnprob_batch(pos)
+            raise SystemExit("a failed context accepted another call")
+        except native.NativeError as again:
+            assert "failed earlier" in str(again), again
+    print("DEADLINE_OK {0} {1} {2:.2f} :: {3}".format(rank, kind, elapsed, text[:160]), flush=True)
+    os._exit(3)                       # report and leave: destructors would wait for streams that never finish
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "single":
         single(int(sys.argv[2]))
+    elif sys.argv[1] == "deadline":
+        if sys.argv[2] == "hang" and os.environ.get("RANK") == "1":
+            os.environ["FAKE_RCCL_HANG_AT_CALL"] = "2"           # call 1: the healthy evaluation
+            os.environ["FAKE_RCCL_HANG_MS"] = "60000"
+        deadline(sys.argv[2])
     else:
         rank_mode()

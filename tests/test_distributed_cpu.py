@@ -82,3 +82,51 @@ def test_host_group_explicit_port_and_failure_modes(tmp_path):
         HostGroup(0, 2, timeout=1.0, env=env)
     with pytest.raises(HostGroupError):
         HostGroup(1, 2, timeout=1.0, env=env)          # stale rendezvous file of the dead hub: no connection, error
+
+
+@pytest.mark.parametrize("scenario", ["abort", "die"])
+def test_host_group_abort_channel(scenario, tmp_path):
+    """Round 3: a rank that fails tells the host group, and every rank's ``on_abort`` callbacks (in the
+    product: ``Context.abort`` -> ``mcd_ctx_abort``, which ends a wait inside the device all-reduce) run within moments --
+    also when the failing rank just dies without a word.  Afterwards every collective of the group raises."""
+    import socket
+    import textwrap
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = textwrap.dedent("""
+        import os, sys, time, threading
+        sys.path.insert(0, {root!r})
+        from mcmc_dynamics_amd.hostgroup import HostGroup, HostGroupError
+        g = HostGroup.from_env(timeout=60)
+        seen = []
+        flag = threading.Event()
+        g.on_abort(lambda reason: (seen.append(reason), flag.set()))
+        g.barrier()
+        t0 = time.monotonic()
+        if g.rank == 1:
+            if {scenario!r} == "die":
+                os._exit(9)                                   # no goodbye on the control connection
+            g.abort("boom in a block")
+        assert flag.wait(20.0), "no abort arrived"
+        elapsed = time.monotonic() - t0
+        assert elapsed < 5.0, elapsed
+        want = "rank 1: boom in a block" if {scenario!r} == "abort" else "rank 1 closed its control connection"
+        assert want in seen[0], seen
+        try:
+            g.barrier()
+            raise SystemExit("collective after an abort did not raise")
+        except HostGroupError as exc:
+            assert "aborted" in str(exc)
+        print("ABORT_SEEN", g.rank, round(elapsed, 3), flush=True)
+        os._exit(3)                                           # what a failed rank does: report and leave, non-zero
+    """).format(root=ROOT, scenario=scenario)
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="1", MCD_RDZV_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    codes = [p.returncode for p in procs]
+    assert codes == ([3, 3, 3] if scenario == "abort" else [3, 9, 3]), (codes, outs)
+    seen = sorted(o[0].split()[1] for o in outs if o[0].startswith("ABORT_SEEN"))
+    assert seen == (["0", "1", "2"] if scenario == "abort" else ["0", "2"]), outs

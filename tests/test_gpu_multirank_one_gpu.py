@@ -37,3 +37,35 @@ def test_one_process_per_rank_on_one_device(fake_rccl, world):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert "FAKE_RCCL_RANKS_OK world={0}".format(world) in res.stdout
+
+
+@pytest.mark.parametrize("kind", ["hang", "raise", "die"])
+def test_a_collective_that_never_completes_ends_in_an_error_not_a_hang(fake_rccl, kind):
+    """the PRODUCT path (Runner / _native, not the bench harness) has a collective deadline.  Two ranks on
+    one device over the stand-in library, started as plain processes (the launcher would tear the job down at the first
+    non-zero exit): "hang" -- rank 1's all-reduce never completes, both ranks return MCD_ERR_RCCL at collective_timeout_ms;
+    "raise" / "die" -- rank 1 fails inside a block of Runner.__call__ / its process dies, the host group's abort channel
+    reaches rank 0, whose wait inside the resident block ends at once.  Every rank exits non-zero; nothing is re-routed."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1",
+                   MCD_RDZV_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, WORKER, "deadline", kind], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung: {0}".format(kind))
+    codes = [p.returncode for p in procs]
+    assert codes == ([3, 9] if kind == "die" else [3, 3]), (codes, [o[0][-1500:] + o[1][-2500:] for o in outs])
+    assert "DEADLINE_OK 0 " + kind in outs[0][0], outs[0]
+    if kind != "die":
+        assert "DEADLINE_OK 1 " + kind in outs[1][0], outs[1]
