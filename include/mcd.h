@@ -303,6 +303,20 @@ int mcd_last_prefetch(const mcd_catalog* cat);
  * the mixture kernels (no per-star exponent bookkeeping; chunks holding a star outside its domain -- a certain member, an
  * extreme background likelihood, an empty component -- still run the fast formulation); -1 before any call. */
 int mcd_last_fast_level(const mcd_catalog* cat);
+
+/* float32 accuracy domain (MCD_F32, MCD_F32_ACC64).  The float32 kernels round every record field and walker constant to
+ * 24 bits first; they stay within 1e-6 (MCD_F32_ACC64) / 2e-5 (MCD_F32) of the float64 kernels -- fixed centre; 1e-5 /
+ * 1e-4 with a free centre -- on the scale max(|lnL|, N, 32) only while
+ *     kappa_v = (max|v| + |v_sys| + |v_maxx| + |v_maxy|) / sqrt(min(verr^2) + min(sigma^2))      <= 96
+ *     kappa_theta = (|v_maxx| + |v_maxy|) / sqrt(min(verr^2) + min(sigma^2)) * 2^-23 / sep_harm   <= 4e-5   (free centre;
+ *                   sep_harm: harmonic mean angular separation [rad] of the stars from the catalogue's centroid)
+ * and variances, residuals and mixture values lie in the float32 ranges (norm within 2^-15 .. 2^15, |v - v_los| <= 2^15,
+ * lnL_bg within -80 .. 60, pmember <= 1 - 2^-20, density and f_back within 2^-20 .. 2^20); derivation in
+ * mcmc_dynamics_amd/csrc/mcd_guard.h (f32_domain), evidence in profiles/r03_fuzz_f32.txt (tools/fuzz_f32.py: errors up to
+ * 8.5e-4 outside on its ranges, 0.58 in the wider campaign of round 2).  A parameter table outside the domain is REFUSED: mcd_params_upload / mcd_loglike_batch return
+ * MCD_ERR_INVALID with the reason (option "f32_domain" = 0: evaluate regardless).  mcd_last_f32_domain reports the verdict
+ * on the last staged table (1 inside, 0 outside; always 1 for MCD_F64 catalogues) and the two condition numbers. */
+int mcd_last_f32_domain(const mcd_catalog* cat, double* kappa_v, double* kappa_theta);
 /* Launch geometry of the main kernel for the last call: workgroups, walker tile (walkers that
  * reuse one star record load), chunks per parameter set, bytes per star record. */
 int mcd_last_launch_info(const mcd_catalog* cat, int64_t* n_workgroups, int32_t* walker_tile,

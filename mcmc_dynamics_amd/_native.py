@@ -63,6 +63,7 @@ SYMBOLS = {
     "mcd_rerun_count": (ctypes.c_int64, [ctypes.c_void_p]),
     "mcd_last_prefetch": (ctypes.c_int, [ctypes.c_void_p]),
     "mcd_last_fast_level": (ctypes.c_int, [ctypes.c_void_p]),
+    "mcd_last_f32_domain": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p]),
     "mcd_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "mcd_last_launch_info": (ctypes.c_int, [ctypes.c_void_p, _c_int64_p, ctypes.POINTER(ctypes.c_int32), _c_int64_p,
                                             ctypes.POINTER(ctypes.c_int32)]),
@@ -451,6 +452,18 @@ class Catalog(object):
     def fast_level(self):
         """Kernel family of the batch staged last: 0 plain, 1 fast, 2 narrow-range fixed-background variant."""
         return self.lib.mcd_last_fast_level(self.handle)
+
+    @property
+    def f32_in_domain(self):
+        """Was the table staged last inside the float32 accuracy domain (include/mcd.h)?  Always True for float64."""
+        return bool(self.lib.mcd_last_f32_domain(self.handle, None, None))
+
+    @property
+    def f32_condition(self):
+        """(kappa_v, kappa_theta) of the table staged last: the two condition numbers the float32 domain bounds."""
+        kv, kt = ctypes.c_double(), ctypes.c_double()
+        self.lib.mcd_last_f32_domain(self.handle, ctypes.byref(kv), ctypes.byref(kt))
+        return kv.value, kt.value
 
     def launch_info(self):
         wg, ch = ctypes.c_int64(), ctypes.c_int64()

@@ -223,6 +223,9 @@ struct mcd_catalog {
     int prefetch = -1;                 // option "prefetch": -1 by record volume (>= 8 MiB per device), 0 off, 1 on
     int balance = -1;                  // option "balance": one round of equal waves (mcd_chunks.h): -1 when the catalogue is
                                        // small enough, 0 never, m > 0 forced with m workgroups per CU
+    int f32_domain = 1;                // option "f32_domain": 1 calls outside the float32 accuracy domain (mcd_guard.h) are refused
+                                       // with MCD_ERR_INVALID, 0 they are evaluated anyway (mcd_last_f32_domain tells)
+    mcd::F32Domain last_f32;           // verdict on the last staged parameter table (float32 catalogues)
     int combine = 1;                   // option "combine": balanced plans may use 8- / 16-wave workgroups that combine their
                                        // chunks' sums: 0 never, 1 the largest the plan allows, 8 / 16 at most that many waves
     // state of the last evaluation
@@ -508,6 +511,13 @@ int stage_params_impl(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
         return fail(MCD_ERR_INVALID, buf);
     }
     const int64_t n_rows = cat->n_psets * n_walkers;
+    if (cat->precision != MCD_F64) {
+        // float32 catalogues: is this table inside the domain in which float32 keeps the stated tolerances?
+        cat->last_f32 = mcd::f32_domain(cat->stats, cat->model, cat->free_centre, cat->k, params, n_rows);
+        if (!cat->last_f32.inside && cat->f32_domain)
+            return fail(MCD_ERR_INVALID, std::string("outside the float32 accuracy domain (use an MCD_F64 catalogue, or option "
+                                                     "f32_domain = 0 to evaluate regardless): ") + cat->last_f32.reason);
+    }
     const int fast = fast_level(cat, params, n_rows);
     for (Shard& sh : cat->shards) {
         WorkSet* w = nullptr;
@@ -1352,7 +1362,9 @@ static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::uni
     }
 
     // range statistics for the fast-path guard
-    cat->stats = mcd::compute_stats(d->n_stars, d->v, d->verr, d->lnlike_bg, d->pmember, d->density, bgk);
+    cat->stats = mcd::compute_stats(d->n_stars, d->v, d->verr, d->lnlike_bg, d->pmember, d->density, bgk,
+                                    cat->precision != MCD_F64 ? d->ra : nullptr, d->dec, !cat->free_centre, d->ra_center,
+                                    d->dec_center);
 
     // contiguous star shards, one per device of this process
     const int n_dev = (int)ctx->slots.size();
@@ -1652,6 +1664,7 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     if (!std::strcmp(key, "fused_reduce")) { cat->fused_reduce = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "f32_domain")) { cat->f32_domain = value != 0; return MCD_OK; }
     if (!std::strcmp(key, "prefetch")) {
         if (value < -1 || value > 1) return fail(MCD_ERR_INVALID, "prefetch: -1 (by record volume, default), 0 (off) or 1 (on)");
         cat->prefetch = (int)value;
@@ -1723,6 +1736,14 @@ int mcd_stretch_info(const mcd_catalog* cat, int64_t* device_blocks, int64_t* ho
 }
 
 int mcd_last_prefetch(const mcd_catalog* cat) { return cat ? cat->last_prefetch : -1; }
+
+int mcd_last_f32_domain(const mcd_catalog* cat, double* kappa_v, double* kappa_theta) {
+    if (!cat) return -1;
+    if (kappa_v) *kappa_v = cat->last_f32.kappa_v;
+    if (kappa_theta) *kappa_theta = cat->last_f32.kappa_theta;
+    if (cat->precision == MCD_F64) return 1;
+    return cat->last_f32.inside ? 1 : 0;
+}
 
 int mcd_last_fast_level(const mcd_catalog* cat) {
     if (!cat || cat->cur_walkers <= 0 || cat->shards.empty()) return -1;

@@ -31,6 +31,9 @@ struct CatalogStats : StatsScalars {
     // Stars that rule out the narrow-range variants for the CHUNK that holds them (narrow_exception below), ascending
     // indices; the kernel then takes the general fast form for those chunks only (LaunchShape::chunk_general).
     std::vector<int64_t> narrow_exceptions;
+    // float32 accuracy domain (f32_domain below), gathered when the positions are given: reference point (the fixed centre,
+    // else the catalogue's centroid) [deg], harmonic mean [rad] and maximum [arcsec] of the stars' angular separations from it
+    double ref_ra = 0.0, ref_dec = 0.0, sep_harm = 0.0, r_max_arcsec = 0.0;
 };
 
 // BGFIXED: a certain member (pmember == 1: the mixture value y = (1 - p) + ... has no floor) or lnL_bg < -60 (y can
@@ -45,8 +48,28 @@ inline bool narrow_exception(int bg, double lnbg, double pm, double rho) {
 
 // Gathered once at upload from the host columns (runner.py:261: norm = verr*verr + sigma*sigma).
 inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr, const double* lnbg,
-                                  const double* pmember, const double* density, int bg) {
+                                  const double* pmember, const double* density, int bg, const double* ra = nullptr,
+                                  const double* dec = nullptr, bool fixed_centre = false, double ra_c = 0.0,
+                                  double dec_c = 0.0) {
     CatalogStats st;
+    if (ra && dec && n > 0) {
+        double mr = ra_c, md = dec_c;
+        if (!fixed_centre) {
+            mr = md = 0.0;
+            for (int64_t i = 0; i < n; ++i) { mr += ra[i]; md += dec[i]; }
+            mr /= (double)n; md /= (double)n;
+        }
+        const double kDeg = 0.017453292519943295, cd = std::cos(md * kDeg);
+        double inv = 0.0, far = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            const double sep = std::hypot((ra[i] - mr) * cd, dec[i] - md) * kDeg;
+            inv += 1.0 / std::max(sep, 1e-9);                      // (a star on the reference point: 2e-4 arcsec)
+            far = std::max(far, sep);
+        }
+        st.ref_ra = mr; st.ref_dec = md;
+        st.sep_harm = inv > 0.0 && std::isfinite(inv) ? (double)n / inv : 0.0;
+        st.r_max_arcsec = std::isfinite(far) ? far / kDeg * 3600.0 : kInfinity;
+    }
     double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
     double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
     bool finite = true, ok = true;
@@ -259,6 +282,72 @@ MCD_HD int level_verdict(const StatsScalars& st, int model, bool f32, int64_t n_
         g.nb_min >= lo && g.nb_max <= hi && g.d_max * g.d_max <= 2.0e6 * ParamRanges::lesser(g.n_min, g.nb_min))
         return 2;
     return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// float32 accuracy domain (MCD_F32, MCD_F32_ACC64; host only -- the resident chain is float64).  The float32 kernels round
+// every record field and every walker constant to 24 bits before the first operation, so what they can deliver is set by
+// how strongly the per-star terms amplify those roundings, not by the formulation.  Derived from a campaign of 138 000
+// random cases against the float64 kernels (tools/fuzz_f32.py, profiles/r03_fuzz_f32*.txt; error on the scale
+// max(|lnL|, N, 32) -- a single float32 term has an absolute floor of a few 1e-6):
+//   * RANGES: variances, residuals and mixture values inside the ranges the float32 fast formulations were built for
+//     (guard_verdict with f32 = true: 2^-15 <= norm <= 2^15, |v - v_los| <= 2^15, lnL_bg in [-80, 60], pmember <=
+//     1 - 2^-20, density and f_back in [2^-20, 2^20], every mixture value in [2^-30, 2^30]).  Outside them the literal
+//     float32 log-sum-exp of the plain kernels is what runs, and it is off by up to 3.5e-4 for the mixture models.
+//   * kappa_v = d_max / sqrt(n_min), d_max = max|v| + |v_sys| + |v_maxx| + |v_maxy| (+ |v_back|), n_min the smallest total
+//     variance: the residual d = v - v_los is a difference of numbers of size d_max, its rounding error 2^-24 d_max enters
+//     through (d / sqrt n)^2.  Inside the ranges the campaign finds <= 2.5e-7 (float64 sums) / 3.7e-7 (float32 sums) for
+//     kappa_v <= 96 and up to 1.2e-6 beyond (systemic velocities of 1000 km/s with dispersions of 1 km/s; a walker at
+//     sigma -> 0): the float64 kernels are the tool there.
+//   * FREE centre: the tangent-plane offsets are differences of O(1) products, their absolute error 2^-23 rad becomes a
+//     position-angle error 2^-23 / separation, which the rotation term amplifies by v_rot / sqrt n.  Summed over the
+//     catalogue:  kappa_theta = (max(|v_maxx| + |v_maxy|) / sqrt(n_min)) 2^-23 / sep_harm, sep_harm the harmonic mean
+//     separation [rad] of the stars from the catalogue's centroid (CatalogStats).  Errors reach 8.5e-4 for compact
+//     catalogues with strong rotation and scale like 0.25 kappa_theta at worst: kappa_theta <= 4e-5 keeps them below 1e-5.
+// Stated tolerances inside the domain: fixed centre 1e-6 (MCD_F32_ACC64) / 2e-5 (MCD_F32: the float32 sums of 1e6 terms
+// add to the per-term error, tests/test_gpu_baseline_shapes.py); free centre 1e-5 / 1e-4.
+constexpr double kF32KappaV = 96.0;
+constexpr double kF32KappaTheta = 4.0e-5;
+
+struct F32Domain {
+    bool inside = false;
+    double kappa_v = 0.0, kappa_theta = 0.0;
+    const char* reason = "";
+};
+
+inline F32Domain f32_domain(const CatalogStats& st, int model, bool free_centre, int k, const double* params, int64_t n_rows) {
+    F32Domain out;
+    ParamRanges pr;
+    double rot = 0.0, a_min = kInfinity, off_max = 0.0;
+    const bool prof = is_profile(model);
+    const int ix = prof ? 3 : 2, ic = prof ? 6 : 4;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const double* p = params + i * k;
+        pr.add_row(p, k, model, free_centre);
+        rot = ParamRanges::greater(rot, std::fabs(p[ix]) + std::fabs(p[ix + 1]));
+        if (prof) a_min = ParamRanges::lesser(a_min, p[2]);
+        if (free_centre)        // how far this row's centre is from the reference point of the catalogue statistics [arcsec]
+            off_max = ParamRanges::greater(off_max, std::hypot((p[ic] - st.ref_ra) * std::cos(st.ref_dec * 0.017453292519943295),
+                                                               p[ic + 1] - st.ref_dec) * 3600.0);
+    }
+    GuardRanges g;
+    const bool ranges_ok = guard_verdict(st, model, true, n_rows, pr, &g);
+    double n_min = g.n_min;
+    if (prof && st.r_max_arcsec > 0.0 && a_min > 0.0 && a_min < kInfinity) {
+        // guard_verdict bounds the variance of the profile models by verr^2 alone (the Plummer dispersion decays to 0 at
+        // large r); within THIS catalogue it is at least sigma_max^2 a / sqrt(a^2 + R^2) at the outermost star
+        const double R = st.r_max_arcsec + off_max;
+        const double floor2 = pr.s2_min * a_min / std::sqrt(a_min * a_min + R * R);
+        if (floor2 > 0.0 && floor2 < kInfinity) n_min += floor2;
+    }
+    if (bg_kind(model) == BG_GAUSS) n_min = ParamRanges::lesser(n_min, g.nb_min);
+    out.kappa_v = n_min > 0.0 ? g.d_max / std::sqrt(n_min) : kInfinity;
+    out.kappa_theta = free_centre ? (st.sep_harm > 0.0 && n_min > 0.0 ? rot / std::sqrt(n_min) * 0x1p-23 / st.sep_harm : kInfinity) : 0.0;
+    if (!ranges_ok) out.reason = "variances, residuals or mixture values outside the float32 ranges (norm within 2^-15 .. 2^15, |v - v_los| <= 2^15, lnL_bg within -80 .. 60, pmember <= 1 - 2^-20, density and f_back within 2^-20 .. 2^20)";
+    else if (!(out.kappa_v <= kF32KappaV)) out.reason = "(max|v| + |v_sys| + |v_maxx| + |v_maxy|) / sqrt(min(verr^2) + sigma^2) exceeds 96: the float32 rounding of the velocities is amplified beyond the stated tolerance";
+    else if (free_centre && !(out.kappa_theta <= kF32KappaTheta)) out.reason = "free centre: rotation amplitude over dispersion times 2^-23 / (harmonic mean separation of the stars) exceeds 4e-5: the float32 tangent-plane offsets are too coarse for this catalogue";
+    else out.inside = true;
+    return out;
 }
 
 inline ParamRanges table_ranges(int model, bool free_centre, int k, const double* params, int64_t n_rows) {

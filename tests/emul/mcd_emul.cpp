@@ -2,6 +2,7 @@
 // so that the fast-path algebra (fraction tree, log-product, rsqrt/exp mixture) can be checked against
 // the golden vectors and the oracle without a GPU.  Never loaded by the product package.
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "mcd_chunks.h"
@@ -113,6 +114,18 @@ extern "C" int emul_fast_guard(int model, int free_centre, int f32, int64_t n, c
                                const double* params, int64_t n_rows) {
     const CatalogStats st = compute_stats(n, v, verr, lnbg, pmember, density, bg_kind(model));
     return fast_level(st, model, free_centre != 0, f32 != 0, k, params, n_rows);
+}
+
+// float32 accuracy domain (csrc/mcd_guard.h: f32_domain): verdict, the two condition numbers and the reason
+extern "C" int emul_f32_domain(int model, int free_centre, int64_t n, const double* ra, const double* dec, const double* v,
+                               const double* verr, const double* lnbg, const double* pmember, const double* density, int k,
+                               const double* params, int64_t n_rows, double* kappa, char* reason, int reason_cap,
+                               double ra_c, double dec_c) {
+    const CatalogStats st = compute_stats(n, v, verr, lnbg, pmember, density, bg_kind(model), ra, dec, free_centre == 0, ra_c, dec_c);
+    const F32Domain d = f32_domain(st, model, free_centre != 0, k, params, n_rows);
+    kappa[0] = d.kappa_v; kappa[1] = d.kappa_theta; kappa[2] = st.sep_harm;
+    if (reason && reason_cap > 0) { std::strncpy(reason, d.reason, reason_cap - 1); reason[reason_cap - 1] = 0; }
+    return d.inside ? 1 : 0;
 }
 
 // background.SingleStars: the device's per-lane slice arithmetic (KdeLane) and the slice combination of

@@ -229,3 +229,24 @@ def sharded_loglike(cat, params, model, centre, level, n_shards, bin_offsets=Non
                                 ctypes.byref(n_general))
     assert rc == 0
     return (out[0] if n_psets == 1 else out), n_general.value
+
+
+def f32_domain(cat, params, model, centre=None):
+    """csrc/mcd_guard.h: f32_domain on host columns and a C-ABI-ordered table: (inside, kappa_v, kappa_theta, sep_harm, reason).
+    ``centre=None``: free centre (the table then carries the centre columns)."""
+    L = lib()
+    n = len(cat["v"])
+    cols = {k: (np.ascontiguousarray(cat[k], dtype=np.float64) if k in cat and cat[k] is not None else None)
+            for k in ("ra", "dec", "v", "verr", "lnlike_bg", "pmember", "density")}
+    ptr = lambda a: a.ctypes.data if a is not None else None
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    kappa = np.zeros(3)
+    reason = ctypes.create_string_buffer(400)
+    L.emul_f32_domain.restype = ctypes.c_int
+    L.emul_f32_domain.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 7 + \
+        [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    rc_, dc_ = (0.0, 0.0) if centre is None else (float(centre[0]), float(centre[1]))
+    inside = L.emul_f32_domain(int(model), int(centre is None), n, ptr(cols["ra"]), ptr(cols["dec"]), ptr(cols["v"]),
+                               ptr(cols["verr"]), ptr(cols["lnlike_bg"]), ptr(cols["pmember"]), ptr(cols["density"]),
+                               p.shape[1], p.ctypes.data, p.shape[0], kappa.ctypes.data, reason, 400, rc_, dc_)
+    return bool(inside), float(kappa[0]), float(kappa[1]), float(kappa[2]), reason.value.decode()

@@ -220,7 +220,13 @@ def test_model_fit(which):
     mf.close()
     mf._precision = "f32acc64"
     ok = np.isfinite(g["lnprob"])
-    assert rel_err(mf.lnlike_batch(g["values"][ok]), g["lnprob"][ok]) < 1e-5
+    try:
+        got = mf.lnlike_batch(g["values"][ok])
+    except Exception as exc:                               # this small golden catalogue may lie outside the float32 accuracy domain
+        assert "float32 accuracy domain" in str(exc), exc
+        mf._ensure_catalog().set_option("f32_domain", 0)
+        got = mf.lnlike_batch(g["values"][ok])
+    assert rel_err(got, g["lnprob"][ok]) < 1e-5
 
 
 @pytest.mark.parametrize("which", ["fixed", "free"])

@@ -99,3 +99,50 @@ def test_guard_refuses_what_the_fast_paths_cannot_represent():
     assert emul.fast_guard(tame, pt, 1, CENTRE, f32=True)
     assert not emul.fast_guard(dict(tame, lnlike_bg=np.full(len(cat1["v"]), -70.0)), pt, 1, CENTRE, f32=True)   # y would leave float range
     assert emul.fast_guard(cat, params, 0, CENTRE, f32=True) in (True, False)
+
+
+def test_float32_accuracy_domain():
+    """Round 3: the domain in which the float32 modes keep their stated tolerances (csrc/mcd_guard.h:
+    f32_domain; derived from tools/fuzz_f32.py, profiles/r03_fuzz_f32.txt) -- verdicts, condition numbers and reasons on the
+    host; the enforcement in the library is tests/test_gpu_baseline_shapes.py."""
+    from mcmc_dynamics_amd import synthetic
+    from mcmc_dynamics_amd.background import Gaussian
+    c = synthetic.make_catalog(20000, config=3, background=True)
+    centre = (synthetic.CENTER_RA_DEG, synthetic.CENTER_DEC_DEG)
+    c["lnlike_bg"] = Gaussian(20.0, 40.0)(c["v"], c["verr"])
+    pos = synthetic.make_walkers(64, ["v_sys", "sigma_max", "v_maxx", "v_maxy"], c["truth"], config=3)
+    inside, kv, kt, sep, why = emul.f32_domain(c, pos, 1, centre)
+    assert inside and why == "" and 5 < kv < 60 and kt == 0.0                     # the C3 shape is well inside
+    expect = (np.abs(c["v"]).max() + np.max(np.abs(pos[:, 0]) + np.abs(pos[:, 2]) + np.abs(pos[:, 3]))) / \
+        np.sqrt((c["verr"] ** 2).min() + (pos[:, 1] ** 2).min())
+    assert abs(kv - expect) < 1e-9 * expect
+    # a systemic velocity of 3000 km/s with the same dispersion: the residual is a difference of large numbers
+    far = dict(c, v=c["v"] + 3000.0)
+    shifted = pos.copy()
+    shifted[:, 0] += 3000.0
+    inside, kv, _, _, why = emul.f32_domain(far, shifted, 1, centre)
+    assert not inside and kv > 96 and "exceeds 96" in why
+    # one walker at sigma -> 0
+    tiny = pos.copy()
+    tiny[3, 1] = 1e-3
+    assert not emul.f32_domain(c, tiny, 1, centre)[0]
+    # a certain member leaves the float32 mixture ranges
+    pm = c["pmember"].copy()
+    pm[5] = 1.0
+    inside, _, _, _, why = emul.f32_domain(dict(c, pmember=pm), pos, 1, centre)
+    assert not inside and "pmember <= 1 - 2^-20" in why
+    # free centre: compact catalogue + strong rotation is outside, a wide field with slow rotation inside
+    free = np.column_stack([pos, np.full(64, centre[0]), np.full(64, centre[1])])
+    inside, _, kt, sep, why = emul.f32_domain(c, free, 0, None)
+    assert sep > 0 and kt > 0
+    assert inside == (kt <= 4e-5) and (inside or "tangent-plane" in why)
+    rng = np.random.default_rng(2)
+    wide = dict(c)
+    sepd = np.abs(rng.normal(0, 0.5, 20000)) + 0.05                                  # degrees
+    th = rng.uniform(-np.pi, np.pi, 20000)
+    wide["ra"] = centre[0] + sepd * np.cos(th) / np.cos(np.radians(centre[1]))
+    wide["dec"] = centre[1] + sepd * np.sin(th)
+    slow = free.copy()
+    slow[:, 2:4] *= 0.05
+    inside, _, kt2, sep2, _ = emul.f32_domain(wide, slow, 0, None)
+    assert inside and kt2 < kt and sep2 > sep

@@ -86,6 +86,8 @@ def main():
                     centre = None
                 g = native.Catalog(ctx, cat["ra"], cat["dec"], cat["v"], cat["verr"], model=model, centre=centre,
                                    precision=a.precision, **kw)
+                if a.precision != "f64":
+                    g.set_option("f32_domain", 0)          # fast vs plain float32 consistency over wide ranges (accuracy: tools/fuzz_f32.py)
                 if a.schedule:
                     g.set_option("target_waves", int(rng.integers(1, 20000)))
                     g.set_option("tail_split", int(rng.integers(0, 3)))
