@@ -43,6 +43,11 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, c
 N_SIMD = 256 * 4
 MAX_CLOCK_HZ = 2.4e9
 VALU_F64_PEAK = N_SIMD * MAX_CLOCK_HZ / 4.0          # 6.144e11 wave-instructions / s
+# float32 vector instructions issue at twice that rate: tools/valu_rate_probe.hip measures 1.04 ns per wave64 v_fma_f32 /
+# v_mul_f32 / v_add_f32 per SIMD against 2.35 ns for v_fma_f64 in the same run (profiles/r03_valu_rate_probe.txt), i.e. 2
+# cycles against 4 -- the chip table's 157.3 TFLOP/s of vector f32 against 78.6 TFLOP/s of f64; v_pk_fma_f32 is no faster
+# per float.  The roof of the MCD_F32 / MCD_F32_ACC64 kernels (the f64 additions of the latter cost two such slots).
+VALU_F32_PEAK = N_SIMD * MAX_CLOCK_HZ / 2.0          # 1.2288e12 wave-instructions / s
 COLLECTIVE_TIMEOUT_S = 180
 EXIT_COLLECTIVE = 3
 ISA_MIX = os.path.join(ROOT, "mcmc_dynamics_amd", "csrc", "isa_mix.json")
@@ -672,6 +677,11 @@ def main():
             roofline = {
                 "bound": "valu_f64", "achieved": achieved, "peak": VALU_F64_PEAK, "unit": "VALU wave-instructions/s",
                 "frac": achieved / VALU_F64_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_note": None if traffic is None else
+                "FETCH_SIZE is tallied in 64-byte units whether the request was 64 or 128 bytes (MI355X_MICROARCH.md); "
+                "tools/summarize_rocprof.py takes the factor (x1 / x2) that reproduces the one byte count that is known -- the "
+                "compulsory read of the record array -- so the figure is CALIBRATED on the compulsory traffic and cannot "
+                "by itself show over-fetch beyond a factor 2; WRITE_SIZE needs no correction",
                 "kernel": "mcd::loglike_kernel", "kernel_us": kernel_s * 1e6, "kernel_us_sampled_launches": t["kernel_samples"],
                 "kernel_us_first_20_launches_after_idle": t["cold_kernel_us"],
                 "valu_per_term": row["valu_per_term"], "valu_f64_per_term": row["f64_per_term"],
@@ -691,10 +701,28 @@ def main():
             roofline = {"bound": "valu_f64", "achieved": None, "peak": VALU_F64_PEAK, "unit": "VALU wave-instructions/s",
                         "frac": None, "traffic": traffic, "kernel_us": kernel_s * 1e6, "error": src}
     else:
-        roofline = {"bound": "valu_f32", "achieved": None, "peak": None, "unit": "VALU wave-instructions/s", "frac": None,
-                    "traffic": None, "kernel_us": kernel_s * 1e6, "kernel_us_sampled_launches": t["kernel_samples"],
+        # float32 modes (the C5 sweep): the roof is f32 vector-instruction issue, 2 cycles per wave64 instruction
+        row, src = isa_counts(model + "_" + args.precision) if model in ("const", "bgfixed") else (None, "no instruction count for this model in float32")
+        roofline = {"bound": "valu_f32", "achieved": None, "peak": VALU_F32_PEAK, "unit": "VALU wave-instructions/s", "frac": None,
+                    "traffic": None, "kernel": "mcd::loglike_kernel", "kernel_us": kernel_s * 1e6,
+                    "kernel_us_sampled_launches": t["kernel_samples"], "terms_per_launch": local_terms,
+                    "peak_definition": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 f32 vector instruction "
+                                       "(tools/valu_rate_probe.hip: 1.04 ns per v_fma_f32 against 2.35 ns per v_fma_f64, "
+                                       "profiles/r03_valu_rate_probe.txt)",
                     "hbm_streaming_model": {"algorithmic_bytes_per_term": bytes_per_term, "GBps": streaming_gbps,
                                             "frac_of_8TBps": streaming_gbps / HBM_PEAK_GBPS}}
+        if row is not None:
+            prefetching = info.get("prefetch") == 1
+            per_term = row["valu_per_term_prefetch"] if prefetching and "valu_per_term_prefetch" in row else row["valu_per_term"]
+            achieved = per_term * local_terms / 64.0 / kernel_s
+            roofline.update({"achieved": achieved, "frac": achieved / VALU_F32_PEAK, "valu_per_term": per_term,
+                             "valu_f64_per_term": row["f64_per_term"], "prefetching_instantiation": prefetching,
+                             "valu_per_term_source": src,
+                             "note": "achieved = VALU wave-instructions of the hot loop per term x terms / 64 lanes / kernel time, "
+                                     "every instruction counted as one f32 slot (an f64 addition of the f32acc64 sums costs two, "
+                                     "v_rcp_f32 / v_frexp about three: frac is a lower bound of the pipe's occupation)"})
+        else:
+            roofline["error"] = src
 
     out = {
         "metric": "star-walker log-L terms/sec", "value": value, "unit": "terms/s",
@@ -708,6 +736,9 @@ def main():
                                    .format(world, n_walkers * n_bins) if world > 1 else "1 GPU")},
         "roofline": roofline,
         "kernel_us_per_rank": kernel_us_ranks,
+        # SURVEY 8(d)'s own protocol beside `value`: the BLOCKING C-ABI call (parameters in, walker prep, kernels, reduction
+        # [, all-reduce], results out, synchronisation), median of 50 calls after 3 warm-ups
+        "value_blocking": local_terms * world / sync_med,
         "blocking_call_us_median": sync_med * 1e6, "blocking_call_us_mean": sync_mean * 1e6,
         "blocking_call_terms_per_s": local_terms * world / sync_med,
         "launch": info,

@@ -34,6 +34,53 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, double seed) {
     out[blockIdx.x * 256 + threadIdx.x] = s + t;
 }
 
+// float32 counterparts (round 3: the roof of the MCD_F32 / MCD_F32_ACC64 kernels)
+typedef float float2_t __attribute__((ext_vector_type(2)));
+template <int OP>
+__global__ __launch_bounds__(256) void kf(double* out, int iters, float seed) {
+    float a[OPS];
+    float2_t p[OPS];
+    double d[OPS];
+    int ei[OPS];
+#pragma unroll
+    for (int j = 0; j < OPS; ++j) { a[j] = seed + threadIdx.x * 1e-3f + j; p[j] = float2_t{a[j], a[j] + 0.5f}; d[j] = a[j]; ei[j] = 0; }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < OPS; ++j) {
+            if (OP == 0) a[j] = __builtin_fmaf(a[j], 1.0000001f, 1e-9f);
+            if (OP == 1) a[j] = a[j] * 1.0000001f;
+            if (OP == 2) a[j] = a[j] + 1e-9f;
+            if (OP == 3) a[j] = __builtin_amdgcn_rsqf(a[j]) + 2.0f;
+            if (OP == 4) a[j] = __builtin_amdgcn_rcpf(a[j]) + 1.0f;
+            if (OP == 5) a[j] = __builtin_amdgcn_exp2f(a[j] * 0.01f) + 0.5f;
+            if (OP == 6) a[j] = __builtin_amdgcn_logf(a[j]) + 3.0f;
+            if (OP == 7) { int e; a[j] = __builtin_frexpf(a[j], &e) + 1.0f; ei[j] += e; }
+            if (OP == 8) p[j] = __builtin_elementwise_fma(p[j], float2_t{1.0000001f, 0.9999999f}, float2_t{1e-9f, 1e-9f});   // v_pk_fma_f32
+            if (OP == 9) d[j] += (double)a[j], a[j] = a[j] * 1.0000001f;               // f32 mul + cvt + f64 add (the f32acc64 sums)
+            if (OP == 10) a[j] = __builtin_fmaxf(a[j], 1.5f) * 1.0000001f;
+        }
+    }
+    double s = 0; int t = 0;
+#pragma unroll
+    for (int j = 0; j < OPS; ++j) { s += a[j] + p[j].x + p[j].y + d[j]; t += ei[j]; }
+    out[blockIdx.x * 256 + threadIdx.x] = s + t;
+}
+
+template <int OP> double runf(const char* name, double ops_per, double* d) {
+    const int iters = 20000, grid = 256 * 8;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kf<OP><<<grid, 256>>>(d, 100, 1.5f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kf<OP><<<grid, 256>>>(d, iters, 1.5f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double winstr = (double)grid * 4 / 1024 * iters * OPS;
+    double ns_per = ms * 1e6 / winstr;
+    printf("%-36s %8.3f ms   %6.2f ns per loop slot (= %5.1f cycles @2.4GHz), %.0f wave-instruction(s) per slot\n", name, ms, ns_per, ns_per * 2.4, ops_per);
+    return ns_per;
+}
+
 template <int OP> double run(const char* name, double extra_ops_per, double* d) {
     const int iters = 20000, grid = 256 * 8;   // 8 blocks of 4 waves per CU: 8 waves per SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -64,5 +111,17 @@ int main() {
     run<6>("v_rndne_f64 + mul", 1, d);
     run<7>("v_cvt_i32_f64 + add + iadd", 2, d);
     run<9>("v_max_f64 + mul", 1, d);
+    printf("-- float32 --\n");
+    runf<0>("v_fma_f32", 1, d);
+    runf<1>("v_mul_f32", 1, d);
+    runf<2>("v_add_f32", 1, d);
+    runf<8>("v_pk_fma_f32 (2 floats per lane)", 1, d);
+    runf<3>("v_rsq_f32 + add", 2, d);
+    runf<4>("v_rcp_f32 + add", 2, d);
+    runf<5>("v_exp_f32 + mul + add", 3, d);
+    runf<6>("v_log_f32 + add", 2, d);
+    runf<7>("frexp f32 mant+exp + add + iadd", 4, d);
+    runf<9>("f32 mul + v_cvt_f64_f32 + v_add_f64", 3, d);
+    runf<10>("v_max_f32 + mul", 2, d);
     return 0;
 }
