@@ -665,8 +665,8 @@ def main():
 
     roofline = None
     if args.precision == "f64":
-        isa_key = model if model in ("bgfixed", "bggauss") and info["kernel_family"].endswith("narrow-range variant") else \
-            (model + "_general" if model in ("bgfixed", "bggauss") else model)
+        isa_key = model if model in ("bgfixed", "bggauss", "profile") and info["kernel_family"].endswith("narrow-range variant") else \
+            (model + "_general" if model in ("bgfixed", "bggauss", "profile") else model)
         row, src = isa_counts(isa_key)
         if row is not None:
             # the instantiation the timed launches ran: with or without the software prefetch of the records

@@ -1363,8 +1363,8 @@ static int catalog_create_impl(mcd_ctx* ctx, const mcd_catalog_desc* d, std::uni
 
     // range statistics for the fast-path guard
     cat->stats = mcd::compute_stats(d->n_stars, d->v, d->verr, d->lnlike_bg, d->pmember, d->density, bgk,
-                                    cat->precision != MCD_F64 ? d->ra : nullptr, d->dec, !cat->free_centre, d->ra_center,
-                                    d->dec_center);
+                                    cat->precision != MCD_F64 || mcd::is_profile(cat->model) ? d->ra : nullptr, d->dec,
+                                    !cat->free_centre, d->ra_center, d->dec_center);
 
     // contiguous star shards, one per device of this process
     const int n_dev = (int)ctx->slots.size();

@@ -25,6 +25,8 @@ struct StatsScalars {
     bool stats_finite = true;                       // v, verr all finite
     bool extras_ok = true;                          // background columns inside the fast-path ranges
     bool narrow_possible = false;                   // at most 1/8 of the stars are exceptions (else: general form throughout)
+    double r_max_fixed = 0.0;                       // fixed centre: largest separation of a star from it [arcsec] (0: unknown /
+                                                    // free centre) -- bounds r_peak^2 + r^2 for the narrow-range profile variant
 };
 
 struct CatalogStats : StatsScalars {
@@ -69,6 +71,9 @@ inline CatalogStats compute_stats(int64_t n, const double* v, const double* verr
         st.ref_ra = mr; st.ref_dec = md;
         st.sep_harm = inv > 0.0 && std::isfinite(inv) ? (double)n / inv : 0.0;
         st.r_max_arcsec = std::isfinite(far) ? far / kDeg * 3600.0 : kInfinity;
+        // (small-angle separation against the exact tangent-plane radius of the records: 1 + 1e-5 within a degree; the
+        // narrow-range bound below has a factor 4 to spare)
+        if (fixed_centre) st.r_max_fixed = st.r_max_arcsec;
     }
     double e2_min = std::numeric_limits<double>::infinity(), e2_max = 0.0, v_abs = 0.0;
     double r_min = std::numeric_limits<double>::infinity(), r_max = 0.0;
@@ -268,6 +273,13 @@ MCD_HD int level_verdict(const StatsScalars& st, int model, bool f32, int64_t n_
     GuardRanges g;
     if (!guard_verdict(st, model, f32, n_rows, pr, &g)) return 0;
     if (f32) return 1;
+    // MODEL_PROFILE with a fixed centre (ProfileNarrowAcc, mcd_math.h): m = r_peak^2 + r^2 <= 2^34 arcsec^2 (a 36 degree
+    // field), lengths >= 2^-10 arcsec, variances within 2^-30 .. 2^30, residuals below 2^30: the 8-star tree on
+    // ((dv m - K c)^2, m^2 n) stays within 2^+-820
+    if (model == MODEL_PROFILE)
+        return (st.r_max_fixed > 0.0 && pr.len_min >= 0x1p-10 && pr.len_max <= 0x1p16 &&
+                st.r_max_fixed * st.r_max_fixed * 1.1 + pr.len_max * pr.len_max <= 0x1p34 && g.n_min >= 0x1p-30 &&
+                g.n_max <= 0x1p30 && g.d_max <= 0x1p30) ? 2 : 1;
     const double lo = 0x1p-60, hi = 0x1p60;
     // Per-call conditions of the narrow-range variants (the per-star ones are CatalogStats::narrow_exceptions):
     // d_max^2 <= 2e6 n_min keeps the exponent argument above -1.1e6, inside the int range of exp_tab (|u| < 1.4e6) without a clamp.

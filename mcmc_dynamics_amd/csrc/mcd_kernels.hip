@@ -194,7 +194,8 @@ __global__ __launch_bounds__(WAVES * kWave, WAVES > 4 ? 4 : 1) void loglike_kern
         if constexpr (FAST == 2) {
             // a chunk that holds a star outside the narrow-range domain (certain member, extreme background, ...) takes the
             // general fast form; the flag is wave-uniform (one scalar byte load), so this is a scalar branch
-            const bool general = chunk_general != nullptr && chunk_general[chunk_id] != 0;
+            // (the narrow-range profile variant without background has no per-star conditions: no flags, one form)
+            const bool general = bg_kind(MODEL) != BG_NONE && chunk_general != nullptr && chunk_general[chunk_id] != 0;
             if (general) result = chunk_loglike<MODEL, FREE, T, A, 1, PF>(chunk_recs, ch.count, w, denormal, exptab_lds);
             else result = chunk_loglike<MODEL, FREE, T, A, 2, PF>(chunk_recs, ch.count, w, denormal, exptab_lds);
         } else {
@@ -350,7 +351,7 @@ hipError_t launch_precision(hipStream_t s, const LaunchShape& sh, const void* re
                             int64_t n_chunks, const void* wpar, double* partials, int64_t n_walkers) {
     switch (sh.precision) {
         case 0:
-            if constexpr (bg_kind(MODEL) != BG_NONE) {
+            if constexpr (bg_kind(MODEL) != BG_NONE || (MODEL == MODEL_PROFILE && !FREE)) {
                 if (sh.fast == 2)
                     return launch_one<MODEL, FREE, double, double, 2>(s, sh, records, chunks, n_chunks, wpar, partials, n_walkers);
             }

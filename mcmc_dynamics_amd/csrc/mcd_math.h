@@ -309,6 +309,39 @@ struct ConstAcc {          // accumulators of one walker over one chunk (MODEL_C
     MCD_HD double finish(int64_t count) { return -0.5 * (fma_((double)count, kLn2Pi, l.value()) + q); }
 };
 
+// MODEL_PROFILE, narrow-range variant (guard level 2, mcd_guard.h: level_verdict): the Lynden-Bell residual
+//   d = dv - K c / m,   dv = v - v_sys,  c = v_maxx dy - v_maxy dx,  K = 2 r_peak,  m = r_peak^2 + r^2        (model.py:124-127)
+// needs the reciprocal of m in the general fast form (v_rcp_f64 + a residual step: ~5 issue slots per term).  Here the
+// division is left to the fraction tree:  d^2 / n = (dv m - K c)^2 / (m^2 n), i.e. the tree runs on
+// (q', n') = ((dv m - K c)^2, m^2 n) -- two more multiplications instead of the reciprocal -- and since the tree's
+// denominator is now prod m_i^2 n_i, the log term needs  sum log n_i = log prod n'_i - 2 log prod m_i: a second running
+// product (one multiplication per term, one rescale and one log per 8 terms / per chunk).  Ranges (level_verdict): m <=
+// 2^34 arcsec^2, 2^-30 <= n <= 2^30, |dv| <= 2^30: the 8-star denominator stays within 2^+-784, the numerator below 2^820.
+struct ProfileNarrowAcc {
+    double q;
+    LogProduct l;          // prod m_i^2 n_i
+    LogProduct lm;         // prod m_i
+    MCD_HD void init() { q = 0.0; l.init(); lm.init(); }
+    MCD_HD void add8(const double* qq, const double* nn, double m_prod) {
+        Frac f = frac_join(frac_join(frac_leaf2(qq[0], nn[0], qq[1], nn[1]), frac_leaf2(qq[2], nn[2], qq[3], nn[3])),
+                           frac_join(frac_leaf2(qq[4], nn[4], qq[5], nn[5]), frac_leaf2(qq[6], nn[6], qq[7], nn[7])));
+        q += f.num * rcp_nr(f.den);
+        l.mul(f.den);
+        l.rescale();
+        lm.mul(m_prod);
+        lm.rescale();
+    }
+    MCD_HD void add1(double q1, double n1, double m1) {
+        q += q1 / n1;
+        l.mul_any(n1);
+        lm.mul_any(m1);
+    }
+    MCD_HD double finish(int64_t count) {
+        const double sum_log_n = l.value() - 2.0 * lm.value();
+        return -0.5 * (fma_((double)count, kLn2Pi, sum_log_n) + q);
+    }
+};
+
 // float32 counterpart (MCD_F32 / MCD_F32_ACC64): groups of 4 stars so that DEN <= 2^60 and NUM <= 2^77 stay inside the
 // f32 range under the host guard 2^-15 <= n <= 2^15, q <= 2^30.  The quotient sum accumulates in A (float or double).
 struct FracF { float num, den; };
@@ -815,7 +848,9 @@ template <class T> MCD_HD T sqrt_(T x) {
 //   CONST   (constant.py:52-111): v_los = v_sys + v_maxx sin(theta) - v_maxy cos(theta), sigma_los = sigma_max
 //   PROFILE (model.py:93-180):    v_los = v_sys + 2 r_peak (v_maxx dy - v_maxy dx) / (r_peak^2 + r^2)
 //                                 sigma_los^2 = sigma_max^2 a / sqrt(a^2 + r^2)           (all lengths in arcsec)
-template <int MODEL, class T, bool FREE, bool FASTMATH = false>
+// NEWTON1 (narrow-range variants of the profile mixtures, f64): the Plummer root from ONE Newton step in its
+// three-instruction form (rsqrt2_newton: low by <= 4.1e-15 relative, see there), two instructions fewer than rsqrt_nr.
+template <int MODEL, class T, bool FREE, bool FASTMATH = false, bool NEWTON1 = false>
 MCD_HD void star_d_n(RecPtr<T> r, const WalkerConsts<T>& w, T& d, T& n) {
     if constexpr (!is_profile(MODEL)) {
         if (FREE) d = free_centre_residual<FASTMATH>(r[2], r[3], r[4], w.sac, w.cac, w.sdc, w.cdc, w.vx, w.vy, r[0] - w.vsys);
@@ -831,7 +866,14 @@ MCD_HD void star_d_n(RecPtr<T> r, const WalkerConsts<T>& w, T& d, T& n) {
             r2 = fma_(dx, dx, dy * dy);
         } else { dx = r[2]; dy = r[3]; r2 = r[4]; }
         T t, inv;
-        if constexpr (FASTMATH && sizeof(T) == 8) {
+        if constexpr (FASTMATH && NEWTON1 && sizeof(T) == 8) {
+            // rsqrt2_newton returns 2 (a^2 + r^2)^-1/2: the factor goes into sigma_max^2 a / 2 (loop-invariant)
+            const T cross = fma_(w.vx, dy, -(w.vy * dx));
+            inv = (T)rcp_nr((double)(w.rp2 + r2));
+            d = fma_(-(w.rp_2 * inv), cross, r[0] - w.vsys);
+            n = fma_(T(0.5) * w.s2a, (T)rsqrt2_newton((double)(w.a2 + r2)), r[1]);
+            return;
+        } else if constexpr (FASTMATH && sizeof(T) == 8) {
             t = (T)rsqrt_nr((double)(w.a2 + r2));
             inv = (T)rcp_nr((double)(w.rp2 + r2));
         } else {
@@ -945,6 +987,38 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
             acc.add1(d * d, n);
         }
         result = acc.finish(count);
+    } else if constexpr (BG == BG_NONE && FAST == 2 && MODEL == MODEL_PROFILE && !FREE) {
+        // narrow-range profile variant (ProfileNarrowAcc): no reciprocal per term, one-step Newton root for the Plummer
+        // dispersion (rsqrt2_newton returns 2 (a^2 + r^2)^-1/2: the factor goes into sigma_max^2 a / 2)
+        ProfileNarrowAcc acc;
+        acc.init();
+        const double hs2a = 0.5 * w.s2a;
+        auto one = [&](RecPtr<double> rr, double& q1, double& n1, double& m1) {
+            m1 = w.rp2 + rr[4];
+            const double t2 = rsqrt2_newton(w.a2 + rr[4]);
+            const double n = fma_(hs2a, t2, rr[1]);
+            const double cross = fma_(w.vx, rr[3], -(w.vy * rr[2]));
+            const double nd = fma_(rr[0] - w.vsys, m1, -(w.rp_2 * cross));
+            q1 = nd * nd;
+            n1 = (m1 * m1) * n;
+        };
+        const int n8 = count >> 3;
+        for (int g = 0; g < n8; ++g, r += 8 * ND) {
+            RecordPrefetch<8 * ND * 8, PF> pf;
+            pf.issue(r + MCD_PREFETCH_DISTANCE * 8 * ND);
+            double qq[8], nn[8], mm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) one(r + j * ND, qq[j], nn[j], mm[j]);
+            const double m_prod = ((mm[0] * mm[1]) * (mm[2] * mm[3])) * ((mm[4] * mm[5]) * (mm[6] * mm[7]));
+            acc.add8(qq, nn, m_prod);
+            pf.retire(acc.q);
+        }
+        for (int j = count & ~7; j < count; ++j, r += ND) {
+            double q1, n1, m1;
+            one(r, q1, n1, m1);
+            acc.add1(q1, n1, m1);
+        }
+        result = acc.finish(count);
     } else if constexpr (BG == BG_NONE && FAST) {
         // fraction-tree + log-product path (f64): 8 stars -> one division, one product factor
         ConstAcc acc;
@@ -1055,7 +1129,7 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
             for (int j = 0; j < 4; ++j) {
                 RecPtr<double> rr = r4 + j * ND;
                 double d, n;
-                star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
+                star_d_n<MODEL, double, FREE, true, NARROW>(rr, w, d, n);
                 acc.add_density<NARROW>(d, n, rr[XB + 2], w.fb, rr[XB + 1], exptab);
             }
         };
@@ -1080,7 +1154,7 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         }
         for (int j = n4 * 4; j < count; ++j, r += ND) {
             double d, n;
-            star_d_n<MODEL, double, FREE, true>(r, w, d, n);
+            star_d_n<MODEL, double, FREE, true, NARROW>(r, w, d, n);
             acc.add_density<NARROW>(d, n, r[XB + 2], w.fb, r[XB + 1], exptab);
             acc.rescale_density();
         }
@@ -1097,7 +1171,7 @@ MCD_HD double chunk_loglike(RecPtr<T> r, int count, const WalkerConsts<T>& w, bo
         acc.init();
         auto one = [&](RecPtr<double> rr) {
             double d, n;
-            star_d_n<MODEL, double, FREE, true>(rr, w, d, n);
+            star_d_n<MODEL, double, FREE, true, NARROW>(rr, w, d, n);
             if constexpr (HALVED) acc.add<true, NARROW>(d, fma_(kScale, rr[1], s2x), rr[0] - w.vb, fma_(kScale, rr[1], sb2x), rr[XB], w.fb, exptab);
             else acc.add<false, NARROW>(d, n, rr[0] - w.vb, rr[1] + w.sb2, rr[XB], w.fb, exptab);
         };

@@ -33,7 +33,7 @@ static void run(int64_t n, const double* recs, const double* wpar, int64_t W, in
                 constexpr int XB = geometry_doubles(MODEL, FREE);
                 constexpr int BG = bg_kind(MODEL);
                 bool general = false;
-                for (int64_t i = s; i < s + count && !general; ++i) {
+                for (int64_t i = s; BG != BG_NONE && i < s + count && !general; ++i) {
                     const double* r = recs + i * ND;
                     general = BG == BG_FIXED ? narrow_exception(BG, r[XB], r[XB + 1], 1.0)
                             : BG == BG_GAUSS ? narrow_exception(BG, 0.0, 0.0, r[XB])
@@ -95,6 +95,7 @@ extern "C" int emul_loglike(int model, int free_centre, int fast, int64_t n, con
     if (fast == 2) {                          // narrow-range variants
 #define NARROW_CASE(M) if (model == M) { if (free_centre) run<M, true, 2>(n, recs, wpar, W, chunk_len, out); else run<M, false, 2>(n, recs, wpar, W, chunk_len, out); return 0; }
         NARROW_CASE(1) NARROW_CASE(2) NARROW_CASE(4) NARROW_CASE(5) NARROW_CASE(6)
+        if (model == 3 && !free_centre) { run<3, false, 2>(n, recs, wpar, W, chunk_len, out); return 0; }   // ProfileNarrowAcc
 #undef NARROW_CASE
     }
     return -1;

@@ -287,6 +287,46 @@ def test_narrow_range_constant_background_profile_variant(which):
     assert emul.fast_level(cat, zero_f, 5, centre) == 1
 
 
+def test_narrow_range_profile_variant_without_reciprocal():
+    """Round 3: ModelFit (model.py:93-222) through ProfileNarrowAcc -- the Lynden-Bell residual's
+    division left to the fraction tree, one-step Newton root for the Plummer dispersion -- against lnprob of the reference
+    (1e-12) and, in 80-bit arithmetic, no further from the exact value than the reference's own float64 evaluation."""
+    from oracle import lnprob_numpy as oracle
+    g = load_golden("model_fit_fixed")
+    cat = {k: g[k] for k in ("ra", "dec", "v", "verr")}
+    centre = (float(g["ra_center"]), float(g["dec_center"]))
+    names = [str(x) for x in g["names"]]
+    ok = np.isfinite(g["lnprob"]) & (g["values"][:, names.index("sigma_max")] > 0)
+    values = emul.abi_columns(g["names"], g["values"], 3, False)[ok]
+    assert ok.sum() >= 6
+    for chunk_len in (64, 248, 100000):
+        narrow = emul.loglike(cat, values, 3, centre, 2, chunk_len)
+        assert rel_err(narrow, g["lnprob"][ok]) < RTOL
+        assert rel_err(narrow, emul.loglike(cat, values, 3, centre, 1, chunk_len)) < 1e-13
+    L = np.longdouble
+    if np.finfo(L).eps < 1e-18:
+        catL = {k: v.astype(L) for k, v in cat.items()}
+        exact = np.array([oracle.faithful_model_lnlike(catL, *row[:6], L(centre[0]), L(centre[1])) for row in values.astype(L)])
+        err_ref = np.max(np.abs((g["lnprob"][ok].astype(L) - exact) / exact)).astype(float)
+        err_narrow = np.max(np.abs((emul.loglike(cat, values, 3, centre, 2, 248).astype(L) - exact) / exact)).astype(float)
+        assert err_narrow < 5e-12 and err_narrow <= 2.0 * err_ref + 1e-15, (err_narrow, err_ref)
+    # wide ranges: random catalogues over the guard's domain of the variant (lengths 2^-10 .. 2^16 arcsec, a degree field)
+    rng = np.random.default_rng(31)
+    for trial in range(30):
+        n = int(rng.integers(1, 700))
+        sv = 10.0 ** rng.uniform(-1, 3)
+        sep = np.abs(rng.normal(0, 10.0 ** rng.uniform(-3, 0), n))
+        th = rng.uniform(-np.pi, np.pi, n)
+        c = {"ra": centre[0] + sep * np.cos(th) / np.cos(np.radians(centre[1])), "dec": centre[1] + sep * np.sin(th),
+             "v": rng.normal(0, sv, n), "verr": sv * 10.0 ** rng.uniform(-2, 1) * rng.lognormal(0, 0.7, n)}
+        w = 7
+        p = np.column_stack([rng.normal(0, sv, w), sv * 10.0 ** rng.uniform(-1.5, 1, w), 10.0 ** rng.uniform(-2.5, 4.5, w),
+                             rng.normal(0, sv, w), rng.normal(0, sv, w), 10.0 ** rng.uniform(-2.5, 4.5, w)])
+        plain = emul.loglike(c, p, 3, centre, 0, 64)
+        narrow = emul.loglike(c, p, 3, centre, 2, 64)
+        assert np.max(np.abs(narrow - plain) / np.maximum(np.abs(plain), n)) < 1e-11, (trial, narrow, plain)
+
+
 @pytest.mark.parametrize("name,model", [("constant_fixed", 0), ("constant_bg_gaussian_fixed", 1), ("constant_gb_fixed", 2)])
 def test_fast_formulations_are_as_accurate_as_the_float64_reference(name, model):
     """Accuracy, not only agreement: against an 80-bit (numpy.longdouble) evaluation of the reference's formulas the fast

@@ -42,7 +42,8 @@ KERNELS = [
     ("ILi1ELb0EddLi2E", "BGFIXED fixed, narrow", "bgfixed", 4, 2, _sel(rsq=4, frexp=0)),
     ("ILi2ELb0EddLi1E", "BGGAUSS fixed centre", "bggauss_general", 4, 1, _sel(rsq=8, frexp=4)),
     ("ILi2ELb0EddLi2E", "BGGAUSS fixed, narrow", "bggauss", 4, 2, _sel(rsq=8, frexp=0)),
-    ("ILi3ELb0EddLi1E", "PROFILE fixed centre", "profile", 8, 1, None),
+    ("ILi3ELb0EddLi1E", "PROFILE fixed centre", "profile_general", 8, 1, None),
+    ("ILi3ELb0EddLi2E", "PROFILE fixed, narrow", "profile", 8, 1, _sel(rsq=8, rcp=1)),
     ("ILi4ELb0EddLi1E", "PROFILE_BGGAUSS fixed", "profile_bggauss", 4, 1, _sel(frexp=4)),
     ("ILi5ELb0EddLi1E", "PROFILE_BGDENS fixed", "profile_bgdens", 4, 1, _sel(frexp=4)),
     ("ILi0ELb0EffLi1E", "CONST fixed, f32", "const_f32", 16, 1, None),
