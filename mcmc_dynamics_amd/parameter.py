@@ -62,13 +62,31 @@ def _allowed_nodes():
     return _ALLOWED_NODES
 
 
+# Attribute names an expression may use, whatever the object: the sampling methods of ``rng`` (numpy.random.Generator), the
+# distribution methods of scipy's ``uniform`` / ``norm`` / ``lognorm``, and value-like attributes / reductions of numbers and
+# arrays.  Everything else is refused -- in particular ``rng.bit_generator`` (whose ``.ctypes`` / ``.cffi`` interfaces hand out
+# raw function pointers: ``rng.bit_generator.ctypes.next_double(12345)`` calls into an arbitrary address).
+_ALLOWED_ATTRIBUTES = frozenset((
+    # numpy.random.Generator
+    "random", "uniform", "normal", "standard_normal", "lognormal", "exponential", "standard_exponential", "gamma",
+    "standard_gamma", "beta", "chisquare", "standard_t", "standard_cauchy", "triangular", "laplace", "logistic", "gumbel",
+    "rayleigh", "weibull", "pareto", "power", "vonmises", "wald", "poisson", "binomial", "integers", "choice", "permutation",
+    # scipy.stats distributions
+    "pdf", "logpdf", "cdf", "logcdf", "sf", "logsf", "ppf", "isf", "rvs", "mean", "median", "std", "var", "interval",
+    # numbers and arrays
+    "real", "imag", "size", "shape", "ndim", "T", "sum", "prod", "min", "max", "clip", "mean", "std"))
+
+
 def check_expression(text):
     """Parse ``text`` and accept only plain arithmetic: numbers, names, arithmetic / comparison / boolean operators,
-    conditional expressions, indexing, tuples / lists, calls and attribute access without leading underscores.  The
+    conditional expressions, indexing, tuples / lists, calls, and the attributes of ``_ALLOWED_ATTRIBUTES``.  The
     reference evaluates these strings with asteval, which refuses dunder attributes and has no ``import`` / ``lambda`` /
     comprehension escape routes into the interpreter; ``eval`` with an empty ``__builtins__`` alone is not a sandbox
     (``().__class__.__base__.__subclasses__()`` reaches ``subprocess.Popen``), so the tree is validated before it is
-    compiled.  Returns the parsed ``ast.Expression``."""
+    compiled.  This is a validator for trusted-but-fallible parameter files, narrower than asteval in what it lets
+    through, not a claim of equivalence with asteval's sandbox.  Integer constants under ``**`` become floats (``9**9**9``
+    is an OverflowError, not an hour of big-integer arithmetic), and a list / tuple literal cannot be repeated with ``*``.
+    Returns the parsed ``ast.Expression``."""
     import ast
     try:
         tree = ast.parse(text.strip(), "<parameter expression>", "eval")
@@ -78,8 +96,16 @@ def check_expression(text):
     for node in ast.walk(tree):
         if not isinstance(node, allowed):
             raise ExpressionError("'{0}' is not allowed in a parameter expression: '{1}'".format(type(node).__name__, text))
-        if isinstance(node, ast.Attribute) and node.attr.startswith("_"):
+        if isinstance(node, ast.Attribute) and (node.attr.startswith("_") or node.attr not in _ALLOWED_ATTRIBUTES):
             raise ExpressionError("attribute '{0}' is not allowed in a parameter expression: '{1}'".format(node.attr, text))
+        if isinstance(node, ast.BinOp) and isinstance(node.op, ast.Mult) and \
+                (isinstance(node.left, (ast.List, ast.Tuple)) or isinstance(node.right, (ast.List, ast.Tuple))):
+            raise ExpressionError("a list / tuple cannot be repeated in a parameter expression: '{0}'".format(text))
+        if isinstance(node, ast.BinOp) and isinstance(node.op, ast.Pow):
+            for side in ("left", "right"):
+                operand = getattr(node, side)
+                if isinstance(operand, ast.Constant) and isinstance(operand.value, int) and not isinstance(operand.value, bool):
+                    setattr(node, side, ast.copy_location(ast.Constant(float(operand.value)), operand))
         if isinstance(node, ast.Name) and node.id.startswith("_"):
             raise ExpressionError("name '{0}' is not allowed in a parameter expression: '{1}'".format(node.id, text))
         if isinstance(node, ast.Constant) and isinstance(node.value, (str, bytes)):

@@ -115,7 +115,11 @@ def test_expressions_cannot_reach_the_interpreter():
     escape = "[c for c in ().__class__.__base__.__subclasses__() if c.__name__=='Popen']"
     for bad in (escape, "().__class__", "rng.__class__.__mro__", "(lambda: 1)()", "__import__('os').system('true')",
                 "getattr(rng, 'bit_generator')", "rng._bit_generator", "norm.__init__.__globals__", "f'{n}'",
-                "rng.normal(size=n).__array_interface__", "{1: 2}", "[x for x in (1, 2)]", "open('/etc/passwd')"):
+                "rng.normal(size=n).__array_interface__", "{1: 2}", "[x for x in (1, 2)]", "open('/etc/passwd')",
+                # public attributes that lead out of the arithmetic (raw function pointers of the bit generator),
+                # unbounded integer powers, memory bombs
+                "rng.bit_generator.ctypes.next_double(12345)", "rng.bit_generator.state", "rng.bit_generator.cffi",
+                "norm.dist", "uniform.logpdf.__func__", "9**9**9", "(9**9)**(9**9)", "[0.0] * 99999999999", "(1, 2) * 99999999999"):
         with pytest.raises(ExpressionError):
             pars["v_sys"].initials = bad
             pars["v_sys"].evaluate_initials(4)
@@ -135,6 +139,10 @@ def test_expressions_cannot_reach_the_interpreter():
     assert pars["v_sys"].evaluate_lnprior(0.5) == pytest.approx(-1.643335713764618)
     pars["v_sys"].lnprior = "0.0 if -5 <= val <= 5 else -inf"
     assert pars["v_sys"].evaluate_lnprior(9.0) == -np.inf
+    pars["v_sys"].lnprior = "-0.5 * (val - 3)**2 / 2**2 + uniform.logpdf(val, loc=-10, scale=20) - log(2**0.5)"
+    assert pars["v_sys"].evaluate_lnprior(1.0) == pytest.approx(-0.5 - np.log(20.0) - 0.5 * np.log(2.0))
+    pars["v_sys"].initials = "clip(rng.normal(size=n), -1, 1).real * 2**1"
+    assert pars["v_sys"].evaluate_initials(6).shape == (6,)
 
 
 def test_unit_handling():
