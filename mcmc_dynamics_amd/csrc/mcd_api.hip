@@ -124,6 +124,7 @@ int load_rccl() {
 struct DeviceSlot {
     int device = 0;
     hipStream_t stream = nullptr;        // kernels, copies
+    hipStream_t stream2 = nullptr;       // second compute lane of pipelined evaluations (WorkSet: two lanes)
     hipStream_t comm_stream = nullptr;   // the per-step all-reduce, so that it overlaps the next step's kernels
     ncclComm_t comm = nullptr;
 };
@@ -145,7 +146,15 @@ struct WorkSet {
     double* d_out = nullptr;           // [n_psets][W] (+ flag word)
     double* d_out2 = nullptr;          // second result buffer: collective mode alternates between the two, so that the
                                        // all-reduce of step i (comm stream) overlaps the kernels of step i + 1
-    int buf = 0;                       // buffer the last enqueue wrote (always 0 without a collective)
+    int buf = 0;                       // buffer the last enqueue wrote (0 for blocking calls without a collective)
+    // Pipelined evaluations on ONE device without a collective alternate between two LANES: lane 0 = the compute stream
+    // with (d_partials, d_out), lane 1 = the second stream with (d_partials2, d_out2).  Consecutive evaluations are
+    // independent (each has its parameters staged), so the reduction and the launch ramp of one overlap the main kernel
+    // of the next instead of sitting between two main kernels on one stream (enqueue(): two_lanes).
+    double* d_partials2 = nullptr;
+    hipEvent_t ev_staged = nullptr;    // parameters staged (on the compute stream): lane 1 waits for it once per staging
+    bool lane1_knows_staging = false;
+    bool lane1_used = false;           // something may be in flight on the second stream
     hipEvent_t ev_reduced[2] = {nullptr, nullptr};   // reduce kernel done, buffer b ready for the all-reduce
     hipEvent_t ev_comm[2] = {nullptr, nullptr};      // all-reduce of buffer b done
     bool comm_pending[2] = {false, false};
@@ -223,6 +232,7 @@ struct mcd_catalog {
     int prefetch = -1;                 // option "prefetch": -1 by record volume (>= 8 MiB per device), 0 off, 1 on
     int balance = -1;                  // option "balance": one round of equal waves (mcd_chunks.h): -1 when the catalogue is
                                        // small enough, 0 never, m > 0 forced with m workgroups per CU
+    int two_lanes = 1;                 // option "two_lanes": pipelined evaluations of one device alternate between two streams
     int f32_domain = 1;                // option "f32_domain": 1 calls outside the float32 accuracy domain (mcd_guard.h) are refused
                                        // with MCD_ERR_INVALID, 0 they are evaluated anyway (mcd_last_f32_domain tells)
     mcd::F32Domain last_f32;           // verdict on the last staged parameter table (float32 catalogues)
@@ -268,6 +278,8 @@ void free_workset(WorkSet& w) {
     if (w.d_partials) (void)hipFree(w.d_partials);
     if (w.d_out) (void)hipFree(w.d_out);
     if (w.d_out2) (void)hipFree(w.d_out2);
+    if (w.d_partials2) (void)hipFree(w.d_partials2);
+    if (w.ev_staged) (void)hipEventDestroy(w.ev_staged);
     for (int b = 0; b < 2; ++b) {
         if (w.ev_reduced[b]) (void)hipEventDestroy(w.ev_reduced[b]);
         if (w.ev_comm[b]) (void)hipEventDestroy(w.ev_comm[b]);
@@ -284,7 +296,8 @@ void free_workset(WorkSet& w) {
 // 6e5 129.5 / 130.7, 1e6 202 / 213;  BGGAUSS 1e5 x 256 58.1 / 46.4;  x 128 walkers: CONST 1e5 15.4 / 9.7, BGFIXED 27.5 /
 // 18.0.  Small catalogues gain because every CU gets the same number of workgroups (1042 workgroups land as 4 or 5 per
 // CU, and the launch waits for the CUs with 5) and because the workgroups add up their chunks' sums themselves; beyond
-// ~1e6 CONST-equivalent stars per 256 walkers the dynamic balancing of 1.5 rounds with a guided tail wins.
+// ~0.9e6 (CONST) .. 1.3e6 (mixtures) CONST-equivalent stars per 256 walkers the dynamic balancing of 1.5 rounds with a
+// guided tail wins.
 // "work" = stars x (walker tiles / 4) x (instructions per term / those of CONST): the thresholds are in CONST stars.
 double model_cost(int model, bool free_centre) {
     static const double kCost[mcd::kNumModels] = {8.5, 24.0, 45.0, 25.0, 60.0, 40.0, 42.0};   // fast f64 loops, DESIGN 3.3
@@ -294,7 +307,10 @@ int balance_auto_m(const mcd_catalog* cat, int64_t n, int64_t n_walkers) {
     const int64_t n_wtiles = (n_walkers + 63) / 64;
     const double tiles = n_wtiles <= 4 ? (double)n_wtiles : 4.0 * (double)((n_wtiles + 3) / 4);
     const double work = (double)n * tiles / 4.0 * model_cost(cat->model, cat->free_centre);
-    if (cat->n_psets != 1 || work > 1.1e6) return 0;
+    // crossover to the multi-round schedules: CONST 1e6 x 256 is 76.4 us multi-round against 78.6 balanced (8e5: 67.0 / 63.3);
+    // the mixtures keep winning a little longer per unit of work (BGFIXED 4e5 stars = 1.1e6 units: 94.0 / 89.7; 6e5: tie)
+    const double limit = mcd::bg_kind(cat->model) == mcd::BG_NONE ? 9.0e5 : 1.3e6;
+    if (cat->n_psets != 1 || work > limit) return 0;
     return work < 6.0e4 ? 2 : (work <= 3.4e5 ? 4 : 8);
 }
 
@@ -366,6 +382,7 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
         if ((e = hipMemset(w.d_out, 0, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&w.d_out2, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMemset(w.d_out2, 0, (size_t)(n_out + 1) * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&w.ev_staged, hipEventDisableTiming)) != hipSuccess) return e;
         for (int b = 0; b < 2; ++b) {
             if ((e = hipEventCreateWithFlags(&w.ev_reduced[b], hipEventDisableTiming)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&w.ev_comm[b], hipEventDisableTiming)) != hipSuccess) return e;
@@ -525,8 +542,12 @@ int stage_params_impl(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
         if (rc != MCD_OK) return rc;
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
-        // the pinned staging buffer may still be in flight from the previous call
+        // the pinned staging buffer (and, on lane 1, the walker constants) may still be in flight from the previous call
         MCD_WAIT(cat->ctx, slot.stream, cat->spin_us, "mcd_params_upload (previous evaluation)");
+        if (w->lane1_used) {
+            MCD_WAIT(cat->ctx, slot.stream2, cat->spin_us, "mcd_params_upload (previous evaluation, second lane)");
+            w->lane1_used = false;
+        }
         std::memcpy(w->h_params, params, (size_t)n_rows * k * sizeof(double));
         // Blocking single-device call: the walker-prep kernel reads the pinned host table over PCIe and the reduce
         // kernel writes the results straight into pinned host memory -- no copy-engine operations on the critical
@@ -540,6 +561,8 @@ int stage_params_impl(mcd_catalog* cat, int64_t n_walkers, int32_t k, const doub
         }
         MCD_HIP(mcd::launch_prepare_walkers(slot.stream, src, n_rows, k, cat->model, cat->free_centre,
                                             cat->precision, w->d_wpar));
+        MCD_HIP(hipEventRecord(w->ev_staged, slot.stream));
+        w->lane1_knows_staging = false;
         w->fast = fast;
         w->staged = true;
     }
@@ -578,13 +601,32 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
         // instead, which travels through the reduce kernel and the all-reduce to every rank.
         const bool coll = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
         double* out_buf = w.mapped ? w.m_out : w.d_out;
-        if (coll) {
-            // alternate result buffers; this step may only overwrite its buffer once the all-reduce that last used it
-            // (two steps ago, on the comm stream) has finished
+        // two lanes: see WorkSet.  (Not with per-launch timing of the harness' plain mode, whose begin / end events
+        // bracket ONE stream; the sampled per-kernel events of "timing" = 2 are recorded on the lane's stream.)
+        const bool two_lanes = pipelined && cat->two_lanes && !(cat->timing && !cat->timing_all);
+        hipStream_t lane_stream = slot.stream;
+        double* lane_partials = w.d_partials;
+        if (coll || two_lanes) {
+            // alternate result buffers (and, with two lanes, streams and partial-sum buffers).  With a collective this step
+            // may only overwrite its buffer once the all-reduce that last used it (two steps ago, on the communication
+            // stream) has finished; the all-reduces themselves stay in order on that one stream.
             w.buf ^= 1;
             out_buf = w.buf ? w.d_out2 : w.d_out;
-            if (w.comm_pending[w.buf]) {
-                MCD_HIP(hipStreamWaitEvent(slot.stream, w.ev_comm[w.buf], 0));
+            if (two_lanes && w.buf) {
+                if (!w.d_partials2) {
+                    const int64_t padded_walkers = (W + 63) / 64 * 64;
+                    MCD_HIP(hipMalloc(&w.d_partials2, std::max<size_t>(1, (size_t)padded_walkers * w.n_chunks) * sizeof(double)));
+                }
+                if (!w.lane1_knows_staging) {
+                    MCD_HIP(hipStreamWaitEvent(slot.stream2, w.ev_staged, 0));
+                    w.lane1_knows_staging = true;
+                }
+                lane_stream = slot.stream2;
+                lane_partials = w.d_partials2;
+                w.lane1_used = true;
+            }
+            if (coll && w.comm_pending[w.buf]) {
+                MCD_HIP(hipStreamWaitEvent(lane_stream, w.ev_comm[w.buf], 0));
                 w.comm_pending[w.buf] = false;
             }
         } else {
@@ -613,19 +655,19 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
             ++sh.ring_used;
         }
         if (cat->timing && !cat->timing_all) MCD_HIP(hipEventRecord(sh.ev_begin, slot.stream));
-        if (cat->timing && sampled) MCD_HIP(hipEventRecord(k0, slot.stream));
-        MCD_HIP(mcd::launch_loglike(slot.stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, w.d_partials, W));
-        if (cat->timing && sampled) MCD_HIP(hipEventRecord(k1, slot.stream));
+        if (cat->timing && sampled) MCD_HIP(hipEventRecord(k0, lane_stream));
+        MCD_HIP(mcd::launch_loglike(lane_stream, shape, sh.records, w.d_chunks, w.n_chunks, w.d_wpar, lane_partials, W));
+        if (cat->timing && sampled) MCD_HIP(hipEventRecord(k1, lane_stream));
         // the fast BGFIXED kernel leaves the walker-independent sum of lnL_bg to the reduction
         const int bgk = mcd::bg_kind(cat->model);
         const double* pset_const =
             (w.fast && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
         {
             const int64_t n_slots = mcd::partial_slots(shape, w.n_chunks, W);
-            MCD_HIP(mcd::launch_reduce(slot.stream, w.d_partials, w.d_offsets, cat->n_psets, n_slots,
+            MCD_HIP(mcd::launch_reduce(lane_stream, lane_partials, w.d_offsets, cat->n_psets, n_slots,
                                        cat->n_psets == 1 ? n_slots : w.max_chunks_per_pset, W, pset_const, out_buf));
         }
-        if (coll && pipelined) MCD_HIP(hipEventRecord(w.ev_reduced[w.buf], slot.stream));
+        if (coll && pipelined) MCD_HIP(hipEventRecord(w.ev_reduced[w.buf], lane_stream));
     }
     // sum the per-device / per-rank partial log-likelihoods: one all-reduce of n_out doubles
     const bool collective = ctx->n_ranks > 1 || ctx->slots.size() > 1 || ctx->force_collective;
@@ -687,6 +729,7 @@ int sync_all(mcd_catalog* cat) {
         const DeviceSlot& slot = cat->ctx->slots[sh.slot];
         MCD_HIP(hipSetDevice(slot.device));
         MCD_WAIT(cat->ctx, slot.stream, cat->spin_us, "mcd_sync / mcd_loglike_fetch (compute stream)");
+        MCD_WAIT(cat->ctx, slot.stream2, cat->spin_us, "mcd_sync / mcd_loglike_fetch (second compute lane)");
         MCD_WAIT(cat->ctx, slot.comm_stream, cat->spin_us, "mcd_sync / mcd_loglike_fetch (communication stream)");
     }
     if (cat->timing && cat->timing_pending) {
@@ -721,7 +764,9 @@ int fetch_once(mcd_catalog* cat, bool* rerun) {
         if (!w.mapped && &sh == &cat->shards[0]) {
             const double* res = w.buf ? w.d_out2 : w.d_out;
             if (w.comm_pending[w.buf]) MCD_HIP(hipStreamWaitEvent(slot.stream, w.ev_comm[w.buf], 0));
-            MCD_HIP(hipMemcpyAsync(w.h_out, res, (size_t)(n_out + 1) * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
+            // (single device, two lanes: the newest results sit behind the work of the lane that produced them)
+            hipStream_t copy_stream = (!coll && w.buf && w.lane1_used) ? slot.stream2 : slot.stream;
+            MCD_HIP(hipMemcpyAsync(w.h_out, res, (size_t)(n_out + 1) * sizeof(double), hipMemcpyDeviceToHost, copy_stream));
         }
     }
     int rc = sync_all(cat);
@@ -819,6 +864,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     WorkSet& w = *wp;
     // nothing of an earlier call may still use the work buffers, the arena or the communicator
     MCD_WAIT(cat->ctx, slot.stream, cat->spin_us, "mcd_stretch_move (previous evaluation)");
+    MCD_WAIT(cat->ctx, slot.stream2, cat->spin_us, "mcd_stretch_move (previous evaluation, second lane)");
     MCD_WAIT(cat->ctx, slot.comm_stream, cat->spin_us, "mcd_stretch_move (previous collective)");
     w.comm_pending[0] = w.comm_pending[1] = false;
     w.staged = false;                     // the walker constants are about to be overwritten on the device
@@ -1142,6 +1188,7 @@ int make_slot(int device, DeviceSlot* slot) {
     int prio_least = 0, prio_greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
     MCD_HIP(hipStreamCreateWithPriority(&slot->comm_stream, hipStreamNonBlocking, prio_greatest));
+    MCD_HIP(hipStreamCreateWithFlags(&slot->stream2, hipStreamNonBlocking));
     return MCD_OK;
 }
 
@@ -1249,6 +1296,7 @@ int mcd_ctx_destroy(mcd_ctx* ctx) {
         if (s.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s.comm);
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.comm_stream) (void)hipStreamDestroy(s.comm_stream);
+        if (s.stream2) (void)hipStreamDestroy(s.stream2);
     }
     delete ctx;
     return MCD_OK;
@@ -1419,6 +1467,7 @@ int mcd_catalog_destroy(mcd_catalog* cat) {
         (void)hipSetDevice(cat->ctx->slots[sh.slot].device);
         (void)hipStreamSynchronize(cat->ctx->slots[sh.slot].stream);
         (void)hipStreamSynchronize(cat->ctx->slots[sh.slot].comm_stream);
+        (void)hipStreamSynchronize(cat->ctx->slots[sh.slot].stream2);
         for (auto& kv : sh.work) free_workset(kv.second);
         if (sh.records) (void)hipFree(sh.records);
         if (sh.d_pset_const) (void)hipFree(sh.d_pset_const);
@@ -1665,6 +1714,12 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
     }
     if (!std::strcmp(key, "fused_reduce")) { cat->fused_reduce = value != 0; return MCD_OK; }
     if (!std::strcmp(key, "f32_domain")) { cat->f32_domain = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "two_lanes")) {
+        int rc = sync_all(cat);
+        if (rc != MCD_OK) return rc;
+        cat->two_lanes = value != 0;
+        return MCD_OK;
+    }
     if (!std::strcmp(key, "prefetch")) {
         if (value < -1 || value > 1) return fail(MCD_ERR_INVALID, "prefetch: -1 (by record volume, default), 0 (off) or 1 (on)");
         cat->prefetch = (int)value;

@@ -28,6 +28,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 rm -rf $O/prof_${TAG}_chain
 timeout -k 10 200 python tools/chain_probe.py > $O/chain_probe_$TAG.txt 2>&1 || { tail -5 $O/chain_probe_$TAG.txt; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_chain -- python3 tools/chain_probe.py 1000000 256 64 > $O/prof_chain_$TAG.log 2>&1 || exit 1
+timeout -k 10 200 python tools/chain_probe.py 100000 256 256 const > $O/chain_probe_c2_$TAG.txt 2>&1 || { tail -5 $O/chain_probe_c2_$TAG.txt; exit 1; }
+rm -rf $O/prof_${TAG}_chain_c2
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_chain_c2 -- python3 tools/chain_probe.py 100000 256 256 const > $O/prof_chain_c2_$TAG.log 2>&1 || exit 1
+for shape in "100000 256 const" "100000 128 const" "100000 256 bgfixed" "1250000 256 const 0,8" "1000000 256 bgfixed 0,8"; do
+    timeout -k 10 200 python tools/balance_sweep.py $shape >> $O/balance_sweep_$TAG.txt 2>&1 || { tail -5 $O/balance_sweep_$TAG.txt; exit 1; }
+done
+timeout -k 10 300 python tools/fuzz_f32.py --seconds 100 --seed 5 > $O/fuzz_f32_$TAG.txt 2>&1 || { tail -5 $O/fuzz_f32_$TAG.txt; exit 1; }
+timeout -k 10 300 python tools/fuzz_gpu.py --seconds 100 --schedule --max-walkers 640 --max-stars 5000 > $O/fuzz_gpu_$TAG.txt 2>&1 || { tail -5 $O/fuzz_gpu_$TAG.txt; exit 1; }
 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 > $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 MCD_CHAIN_PART_BYTES=1 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 7 >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 11 --force-rccl >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
@@ -44,4 +52,12 @@ for set in "$A" "$B" "$C"; do
     rm -rf $O/sq_${TAG}_pass$i
     timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/sq_${TAG}_pass$i -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/sq_${TAG}_pass$i.log 2>&1 || { tail -5 $O/sq_${TAG}_pass$i.log; exit 1; }
 done
+# SQ counters of one float32 launch of the C5 sweep
+i=0
+for set in "$A" "$B" "$C"; do
+    i=$((i+1))
+    rm -rf $O/sqf32_${TAG}_pass$i
+    timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/sqf32_${TAG}_pass$i -- python3 bench.py --workload c5 --precision f32 --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc > $O/sqf32_${TAG}_pass$i.log 2>&1 || { tail -5 $O/sqf32_${TAG}_pass$i.log; exit 1; }
+done
+./tools/valu_rate_probe > $O/valu_rate_probe_$TAG.txt 2>&1 || true
 echo "sweep $TAG complete"
