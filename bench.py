@@ -360,8 +360,28 @@ def timed_steps(gpu_cat, group, steps, warmup, ramp_seconds, stride):
         group.barrier()
         elapsed = float(group.allreduce(np.array([elapsed]), op="max")[0])
     kernel_ms_total, n_launch = gpu_cat.timing_collect()
+    # The same kernel alone on the chip: with two lanes consecutive launches of the timed region overlap, so a
+    # launch's own duration above includes time it shares with its neighbours.  A short pass on ONE lane (untimed for
+    # `value`, every rank alike) gives the duration of a launch that has the SIMDs to itself -- what rocprofv3 reports for
+    # a run with MCD_BENCH_OPTIONS=two_lanes=0 (profiles/: *_kernel_stats_one_lane.txt).
+    one_lane_s, one_lane_n = None, 0
+    try:
+        gpu_cat.set_option("two_lanes", 0)
+        gpu_cat.set_option("timing", 0)
+        for _ in range(8):
+            gpu_cat.enqueue()
+        gpu_cat.set_option("timing", 2)
+        for _ in range(48):
+            gpu_cat.enqueue()
+        gpu_cat.sync()
+        ms1, n1 = gpu_cat.timing_collect()
+        one_lane_s, one_lane_n = ms1 * 1e-3 / max(1, n1), int(n1)
+    finally:
+        gpu_cat.set_option("timing", 0)
+        gpu_cat.set_option("two_lanes", 0 if "two_lanes=0" in (os.environ.get("MCD_BENCH_OPTIONS") or "") else 1)
     return {"elapsed": elapsed, "kernel_s": kernel_ms_total * 1e-3 / max(1, n_launch), "kernel_samples": int(n_launch),
-            "ramp_steps": ramp_steps, "cold_kernel_us": cold_ms * 1e3 / max(1, cold_n)}
+            "ramp_steps": ramp_steps, "cold_kernel_us": cold_ms * 1e3 / max(1, cold_n),
+            "kernel_one_lane_s": one_lane_s, "kernel_one_lane_samples": one_lane_n}
 
 
 def blocking_calls(gpu_cat, pos, n_calls):
@@ -733,10 +753,17 @@ def main():
         period_s = elapsed / args.steps
         roofline["launch_period_us"] = period_s * 1e6
         roofline["frac_by_launch_period"] = roofline["achieved"] * kernel_s / period_s / roofline["peak"]
+        if t.get("kernel_one_lane_s"):
+            roofline["kernel_us_one_lane"] = t["kernel_one_lane_s"] * 1e6
+            roofline["kernel_us_one_lane_sampled_launches"] = t["kernel_one_lane_samples"]
+            roofline["frac_one_lane"] = roofline["achieved"] * kernel_s / t["kernel_one_lane_s"] / roofline["peak"]
         roofline["lanes"] = lanes
         if lanes == 2:
-            roofline["lanes_note"] = ("two lanes: consecutive launches overlap, kernel_us (one launch, start to end) exceeds "
-                                      "launch_period_us (wall time per launch); frac uses kernel_us and is therefore a lower bound")
+            roofline["lanes_note"] = ("two lanes: consecutive launches of the timed region overlap, so kernel_us (one launch, start "
+                                      "to end, shared with its neighbours) exceeds launch_period_us (wall time per launch); frac "
+                                      "uses kernel_us as the contract defines it and is a lower bound; frac_one_lane: the same "
+                                      "launch alone on the chip (a short extra pass on one lane); frac_by_launch_period: "
+                                      "instructions per launch over the steady-state period")
     out = {
         "metric": "star-walker log-L terms/sec", "value": value, "unit": "terms/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": t["ramp_steps"],

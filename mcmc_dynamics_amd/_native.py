@@ -99,7 +99,7 @@ class StretchDesc(ctypes.Structure):
 # Environment switches the library or this binding reads (INTEGRATION.md lists them).  None is needed in production: they
 # select test stand-ins or tuning values, so load_library() says so on the package logger when one is set.
 TEST_SWITCHES = ("MCD_LIB_PATH", "MCD_RCCL_LIBRARY", "MCD_ALLOW_SHARED_DEVICE", "MCD_FORCE_RCCL", "MCD_TARGET_WAVES",
-                 "MCD_CHAIN_PART_BYTES", "MCD_COLLECTIVE_TIMEOUT_MS")
+                 "MCD_CHAIN_PART_BYTES", "MCD_CHAIN_PARTS", "MCD_COLLECTIVE_TIMEOUT_MS")
 
 _lib = None
 _live_catalogs = weakref.WeakSet()

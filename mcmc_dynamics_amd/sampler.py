@@ -19,6 +19,21 @@ kernel launches instead of ~50.
 import numpy as np
 
 
+_DRAW_POOL = None
+
+
+def _draw_pool():
+    """A few helper threads shared by all samplers of the process for the row-wise part of the draws (see ``draw``)."""
+    global _DRAW_POOL
+    if _DRAW_POOL is None:
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            _DRAW_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="mcd-draw")
+        except Exception:                                    # pragma: no cover
+            _DRAW_POOL = False
+    return _DRAW_POOL or None
+
+
 class EnsembleSampler(object):
 
     def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, a=2.0, vectorize=False, seed=None, block_fn=None):
@@ -124,14 +139,34 @@ class EnsembleSampler(object):
         def draw(block):
             # Random numbers for a block of steps in a handful of vectorised draws (the per-step host cost is what limits
             # the sampler once the posterior call takes ~0.1 ms): split of the ensemble = argsort of uniform keys,
-            # stretch factors z ~ g(z) and log acceptance thresholds, partner indices.
-            order_b = np.argsort(rnd.rand(block, self.nwalkers), axis=1)
+            # stretch factors z ~ g(z) and log acceptance thresholds, partner indices.  The generator is consumed in this
+            # order by ONE thread (the stream is the serial one); what follows the raw draws -- the row-wise argsort and the
+            # logarithms, 80 % of the time -- is a pure function of them and is spread over a few threads by rows (NumPy
+            # releases the interpreter lock there): at 1e5 stars a 256-step block of 256 walkers takes the device 9 ms and
+            # one host thread 8 ms to draw.
+            keys = rnd.rand(block, self.nwalkers)
             u = rnd.rand(block, 4, half)
-            zz_b = (am1 * u[:, :2] + 1.0)
-            zz_b *= zz_b
-            zz_b *= inv_a
-            thr_b = np.log(u[:, 2:]) - dm1 * np.log(zz_b)      # accept iff thr < new_lnp - old_lnp
             pick_b = rnd.randint(half, size=(block, 2, half))
+            order_b = np.empty((block, self.nwalkers), dtype=np.int64)
+            zz_b = np.empty((block, 2, half))
+            thr_b = np.empty((block, 2, half))
+
+            def rows(lo, hi):
+                order_b[lo:hi] = np.argsort(keys[lo:hi], axis=1)
+                z = am1 * u[lo:hi, :2] + 1.0
+                z *= z
+                z *= inv_a
+                zz_b[lo:hi] = z
+                thr_b[lo:hi] = np.log(u[lo:hi, 2:]) - dm1 * np.log(z)      # accept iff thr < new_lnp - old_lnp
+
+            workers = _draw_pool()
+            if workers is None or block < 32:
+                rows(0, block)
+            else:
+                n_parts = 4
+                edges = [block * k // n_parts for k in range(n_parts + 1)]
+                for f in [workers.submit(rows, edges[k], edges[k + 1]) for k in range(n_parts)]:
+                    f.result()
             if self.block_fn is not None:
                 return (np.ascontiguousarray(order_b, dtype=np.int32), np.ascontiguousarray(zz_b), np.ascontiguousarray(thr_b),
                         np.ascontiguousarray(pick_b, dtype=np.int32))

@@ -5,9 +5,11 @@
 #     /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/final_sweep.sh TAG'
 set -o pipefail
 TAG=${1:-sweep}
+STAGE=${2:-all}          # a: tests + benches   b: kernel traces + campaigns   c: PMC / SQ counter passes   (a gpurun call lasts <= 20 min)
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
+if [ "$STAGE" = all ] || [ "$STAGE" = a ]; then
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/gpu_tests_$TAG.log 2>&1 || { tail -20 $O/gpu_tests_$TAG.log; exit 1; }
 tail -1 $O/gpu_tests_$TAG.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$TAG.log 2>&1 || { tail -20 $O/smoke_$TAG.log; exit 1; }
@@ -22,9 +24,15 @@ for p in f64 f32acc64 f32; do
 done
 timeout -k 10 200 python tests/probes/kde_probe.py > $O/kde_probe_$TAG.json 2> $O/kde_probe.err || exit 1
 echo "benches done"
+fi
+if [ "$STAGE" = all ] || [ "$STAGE" = b ]; then
 rm -rf $O/prof_${TAG}_c3 $O/prof_${TAG}_c2 $O/pmc_fetch_$TAG $O/pmc_write_$TAG
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c3 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/prof_bench_${TAG}_c3.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c2 -- python3 bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c2.log 2>&1 || exit 1
+# the same two commands on ONE lane (launches do not overlap: the duration of a launch that has the chip to itself)
+rm -rf $O/prof_${TAG}_c3_one_lane $O/prof_${TAG}_c2_one_lane
+MCD_BENCH_OPTIONS=two_lanes=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c3_one_lane -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/prof_bench_${TAG}_c3_one_lane.log 2>&1 || exit 1
+MCD_BENCH_OPTIONS=two_lanes=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c2_one_lane -- python3 bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --no-mcmc > $O/prof_bench_${TAG}_c2_one_lane.log 2>&1 || exit 1
 rm -rf $O/prof_${TAG}_chain
 timeout -k 10 200 python tools/chain_probe.py > $O/chain_probe_$TAG.txt 2>&1 || { tail -5 $O/chain_probe_$TAG.txt; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_chain -- python3 tools/chain_probe.py 1000000 256 64 > $O/prof_chain_$TAG.log 2>&1 || exit 1
@@ -40,6 +48,8 @@ timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 > $O/fuzz_chain_$TAG.l
 MCD_CHAIN_PART_BYTES=1 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 7 >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 11 --force-rccl >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 echo "kernel traces done"
+fi
+if [ "$STAGE" = all ] || [ "$STAGE" = c ]; then
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/pmc_fetch_$TAG.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc --no-c4-strong > $O/pmc_write_$TAG.log 2>&1 || exit 1
 echo "traffic passes done"
@@ -60,4 +70,6 @@ for set in "$A" "$B" "$C"; do
     timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/sqf32_${TAG}_pass$i -- python3 bench.py --workload c5 --precision f32 --steps 20 --warmup 5 --no-cpu-baseline --no-mcmc > $O/sqf32_${TAG}_pass$i.log 2>&1 || { tail -5 $O/sqf32_${TAG}_pass$i.log; exit 1; }
 done
 ./tools/valu_rate_probe > $O/valu_rate_probe_$TAG.txt 2>&1 || true
-echo "sweep $TAG complete"
+./tools/launch_floor_probe > $O/launch_floor_probe_$TAG.txt 2>&1 || true
+fi
+echo "sweep $TAG stage $STAGE complete"
