@@ -425,7 +425,7 @@ def c4_strong(native, synthetic, ctx, group, rank, world, args):
            "terms_per_s": terms * args.steps / t["elapsed"], "ms_per_step": t["elapsed"] / args.steps * 1e3,
            "kernel_us_per_rank": kernel_us, "kernel_us_sampled_launches": t["kernel_samples"],
            "allreduce": ("none (1 rank)" if world == 1 else
-                         "pipelined steps: ncclAllReduce(sum, f64, 256) on the communication stream behind an event, "
+                         "pipelined steps (two compute lanes): ncclAllReduce(sum, f64, 256) on the communication stream behind an event, "
                          "overlapping the next step's kernels (off the critical path); blocking call: on the compute stream "
                          "(on the critical path)"),
            "blocking_call_us_median": med * 1e6, "blocking_call_terms_per_s": terms / med,
@@ -788,7 +788,7 @@ def main():
         "launch": info,
         "mcmc_end_to_end": mcmc,
         "collective": None if world == 1 else {
-            "kind": "ncclAllReduce(sum, f64, count = {0}) per step; pipelined steps run it on a second HIP stream".format(n_walkers * n_bins),
+            "kind": "ncclAllReduce(sum, f64, count = {0}) per step; pipelined steps run it on the communication stream, beside the two compute lanes".format(n_walkers * n_bins),
             "comm_size": comm["size"], "comm_rank_of_rank0": comm["rank"], "rccl_version": comm["rccl_version"],
             "first_allreduce_watchdog_s": COLLECTIVE_TIMEOUT_S,
             # MCD_RCCL_LIBRARY substitutes the collective library (tests/fake_rccl on a single-GPU box): flow check only

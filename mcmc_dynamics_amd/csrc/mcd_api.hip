@@ -359,9 +359,9 @@ int build_workset(mcd_catalog* cat, Shard& sh, int64_t n_walkers, WorkSet** out)
             const bool can16 = mcd::bg_kind(cat->model) != mcd::BG_GAUSS;
             w.waves = 8;
             if (cat->combine == 16 && plan.balanced_m % 4 == 0 && can16) w.waves = 16;
-            // (only for the half ensembles of a sampler, <= 128 walkers: a 256-walker batch is a blocking or pipelined call,
-            // where two 8-wave workgroups are 0.3 us faster -- 1e5 stars x 256 walkers 13.3 against 13.6 us per step)
-            if (cat->combine == 1 && plan.balanced_m == 4 && can16 && n_walkers <= 128) w.waves = 16;
+            // (kernel traces of the C2 bench: 16-wave main kernel 10.7 us + one-wave-per-group reduction 4.6 against 12.0 + 4.0
+            // with 8-wave workgroups and 512 partial sums per walker; wall-clock sweeps put the two within their noise)
+            if (cat->combine == 1 && plan.balanced_m == 4 && can16) w.waves = 16;
         }
     }
     const int64_t padded_walkers = (n_walkers + 63) / 64 * 64;       // partial sums: whole walker tiles (mcd_kernels.hip)

@@ -51,6 +51,10 @@ class EnsembleSampler(object):
         # idles only once per block while the results travel back and the next block goes up, ~0.1 ms).  Part of the
         # definition of the random stream: samplers that should produce the same chain need the same value.
         self.block_steps = 256
+        # ... except the FIRST block of a run with several blocks: its draws cannot overlap anything (nothing runs yet), so it
+        # is kept short -- the device starts after 0.8 ms of draws instead of 3 ms (1e5 stars x 256 walkers: 3 of 39 us per
+        # step over a 1024-step run).  Also part of the definition of the random stream.
+        self.first_block_steps = 64
         self._random = np.random.RandomState(seed)
         self.reset()
 
@@ -184,8 +188,10 @@ class EnsembleSampler(object):
             pool = ThreadPoolExecutor(max_workers=1)
         pending = None
         try:
+            # (the same partition into blocks with and without block_fn: the two then consume the generator alike)
+            first = max(1, min(chunk, int(self.first_block_steps))) if nsteps > chunk else chunk
             while done < nsteps:
-                block = min(chunk, nsteps - done)
+                block = min(first if done == 0 else chunk, nsteps - done)
                 order_b, zz_b, thr_b, pick_b = pending.result() if pending is not None else draw(block)
                 pending = None
                 if pool is not None and done + block < nsteps:

@@ -109,7 +109,7 @@ def sq(out, kernel_sub, terms, dirs):
         "lds_instructions_per_term": mean["SQ_INSTS_LDS"] * 64 / terms,
         "smem_instructions_per_wave": mean["SQ_INSTS_SMEM"] / mean["SQ_WAVES"],
         "lds_active_fraction_of_cu_cycles": mean["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
-        "lds_bank_conflict_fraction_of_lds_active": mean["SQ_LDS_BANK_CONFLICT"] / mean["SQ_LDS_IDX_ACTIVE"],
+        "lds_bank_conflict_fraction_of_lds_active": mean["SQ_LDS_BANK_CONFLICT"] / mean["SQ_LDS_IDX_ACTIVE"] if mean["SQ_LDS_IDX_ACTIVE"] else 0.0,
     }
     data = {"kernel": kernel_sub, "terms_per_launch": terms, "counters_mean_per_launch": mean, "derived": derived,
             "note": "rocprofv3 --pmc, three passes of 8 SQ counters (tools/sq_counters.sh); values are sums over the chip"}
