@@ -632,17 +632,24 @@ def main():
         fit.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)
         fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
         rates = {}
-        for label, block_fn, n_mcmc in (("library", fit._stretch_block, 256), ("numpy_loop", None, 8)):
-            sampler = BinnedSampler(fit.n_bins, n_walkers, fit.n_fitted_parameters, fit.lnprob_batch, seed=5, block_fn=block_fn)
-            state = sampler.run_mcmc(pos, 4 if block_fn is None else 70)
+        # "library": the default (BinnedConstantFit.RNG = "device": numbers generated in the step kernel, csrc/mcd_rng.h);
+        # "host_numbers": the same blocks with NumPy's generator on the host (rng="host"); "numpy_loop": no library blocks
+        for label, block_fn, n_mcmc, rng_mode in (("library", fit._stretch_block, 256, "device"),
+                                                  ("host_numbers", fit._stretch_block, 256, "host"), ("numpy_loop", None, 8, "host")):
+            sampler = BinnedSampler(fit.n_bins, n_walkers, fit.n_fitted_parameters, fit.lnprob_batch, seed=5, block_fn=block_fn,
+                                    rng=rng_mode, seeded_block_fn=fit._stretch_block_seeded if block_fn is not None else None)
+            state = sampler.run_mcmc(pos, 4 if block_fn is None else 256)     # (untimed: also sizes the block arena)
             t2 = time.perf_counter()
             sampler.run_mcmc(state[0], n_mcmc, log_prob0=state[1])
             rates[label] = n_mcmc / (time.perf_counter() - t2)
-            acc = float(np.mean(sampler.acceptance_fraction))
+            if label == "library":
+                acc = float(np.mean(sampler.acceptance_fraction))
+            sampler.close()
         mcmc = {"steps_per_s": rates["library"], "terms_per_s": float(len(cat["v"])) * n_walkers * rates["library"],
                 "driver": "mcmc_dynamics_amd.analysis.binned.BinnedSampler", "posterior": "BinnedConstantFit.lnprob_batch",
                 "ensembles": fit.n_bins, "calls_per_step": 2, "walkers_per_call": n_walkers // 2, "steps": 256,
-                "acceptance_fraction": acc, "numpy_loop_steps_per_s": rates["numpy_loop"],
+                "acceptance_fraction": acc, "random_numbers": "generated in the step kernel (Philox4x64-10, csrc/mcd_rng.h)",
+                "host_numbers_steps_per_s": rates["host_numbers"], "numpy_loop_steps_per_s": rates["numpy_loop"],
                 "stretch_blocks": fit._catalog.stretch_info()}
         fit.close()
 

@@ -242,6 +242,19 @@ int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* desc, int64_t n_s
 /* Blocks of mcd_stretch_move that ran resident on the device / host-driven, blocks the device discarded (they were then
  * run host-driven and count there too) and the status bits of the last discarded one (1 NaN, 2 re-run request, 4 kernel
  * family changed, 8 no proposal inside the prior).  Any pointer may be NULL. */
+/* The same block with its random numbers GENERATED INSIDE the library from a counter-based generator (Philox4x64-10, the
+ * algorithm of numpy.random.Philox; mcmc_dynamics_amd/csrc/mcd_rng.h): the chain is a function of (seed, step, half step,
+ * ensemble, walker) alone -- no numbers cross PCIe, blocks of any length continue each other (step0 = index of the block's first
+ * step), and any step can be replayed on the host: mcd_chain_numbers returns the numbers of steps step0 .. step0 + n_steps - 1 in
+ * the layout mcd_stretch_move takes (order [n_steps][B][W], zz / thr / pick [n_steps][2][B][W/2]), so that
+ * mcd_stretch_move(..., those arrays, ...) gives the same chain bit for bit (tests/test_gpu_device_chain.py).  The logarithms
+ * of the acceptance thresholds are a fixed sequence of IEEE operations (det_log), not libm calls, for that reason.
+ * emcee (analysis/runner.py:403-419) draws from NumPy's Mersenne twister on the host instead. */
+int mcd_stretch_move_seeded(mcd_catalog* cat, const mcd_stretch_desc* desc, int64_t n_steps, double* pos, double* lnp,
+                            uint64_t seed, int64_t step0, double* chain, double* lnprob_chain, int64_t* accepted);
+int mcd_chain_numbers(uint64_t seed, int64_t step0, int64_t n_steps, int64_t n_bins, int64_t n_walkers, int32_t n_dim,
+                      int32_t* order, double* zz, double* thr, int32_t* pick);
+
 int mcd_stretch_info(const mcd_catalog* cat, int64_t* device_blocks, int64_t* host_blocks, int64_t* discarded_blocks,
                      int32_t* last_discard_status);
 

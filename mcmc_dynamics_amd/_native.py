@@ -54,6 +54,11 @@ SYMBOLS = {
     "mcd_stretch_move": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p,
                                         ctypes.POINTER(ctypes.c_int32), _c_double_p, _c_double_p,
                                         ctypes.POINTER(ctypes.c_int32), _c_double_p, _c_double_p, _c_int64_p]),
+    "mcd_stretch_move_seeded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p,
+                                               ctypes.c_uint64, ctypes.c_int64, _c_double_p, _c_double_p, _c_int64_p]),
+    "mcd_chain_numbers": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), _c_double_p, _c_double_p,
+                                         ctypes.POINTER(ctypes.c_int32)]),
     "mcd_stretch_info": (ctypes.c_int, [ctypes.c_void_p, _c_int64_p, _c_int64_p, _c_int64_p, ctypes.POINTER(ctypes.c_int32)]),
     "mcd_last_error": (ctypes.c_char_p, []),
     "mcd_abi_version": (ctypes.c_int, []),
@@ -265,6 +270,25 @@ def default_context():
     return _default_ctx
 
 
+def chain_numbers(seed, step0, n_steps, n_bins, n_walkers, n_dim, squeeze=False):
+    """``mcd_chain_numbers``: the random numbers of steps ``step0 .. step0 + n_steps - 1`` of the seeded chain (host code, no
+    device involved): order (steps, B, W) int32, zz / thr / pick (steps, 2, B, W/2), in the layout ``stretch_move`` takes.
+    ``squeeze``: drop the ensemble axis (n_bins <= 1, a catalogue without bins)."""
+    lib = load_library()
+    b, w = max(int(n_bins), 1), int(n_walkers)
+    order = np.empty((n_steps, b, w), dtype=np.int32)
+    zz = np.empty((n_steps, 2, b, w // 2), dtype=np.float64)
+    thr = np.empty_like(zz)
+    pick = np.empty((n_steps, 2, b, w // 2), dtype=np.int32)
+    rc = lib.mcd_chain_numbers(int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0), int(n_steps), b, w, int(n_dim),
+                               order.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(zz), _ptr(thr),
+                               pick.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    _check(lib, rc, "mcd_chain_numbers")
+    if squeeze:
+        return order[:, 0], zz[:, :, 0], thr[:, :, 0], pick[:, :, 0]
+    return order, zz, thr, pick
+
+
 class Catalog(object):
     """Star records resident in HBM; evaluates the log-likelihood of batches of walkers."""
 
@@ -369,6 +393,26 @@ class Catalog(object):
         _check(self.lib, self.lib.mcd_loglike_per_star(self.handle, p.size, _ptr(p), _ptr(out)), "mcd_loglike_per_star")
         return out
 
+    def _stretch_desc(self, plan, w, p, n_bins):
+        cols = [np.ascontiguousarray(plan["col_source"], dtype=np.int32), _f64(plan["col_const"]), _f64(plan["col_factor"]),
+                _f64(plan["lo"]), _f64(plan["hi"])]
+        if cols[0].size != self.k or cols[1].size != self.k or cols[2].size != self.k or cols[3].size != p or cols[4].size != p:
+            raise ValueError("stretch_move: plan does not match the catalogue / the number of free parameters")
+        d = StretchDesc()
+        d.n_walkers, d.n_dim, d.k, d.n_bins = w, p, self.k, n_bins
+        d.col_source = cols[0].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        d.col_const, d.col_factor, d.lo, d.hi = (_ptr(c) for c in cols[1:])
+        d.fixed_ok = 1 if plan.get("fixed_ok", True) else 0
+        return d, cols                                          # (cols: keeps the arrays the descriptor points to alive)
+
+    @staticmethod
+    def _stretch_outputs(n_steps, lead, w, p, chain, lnprob_chain, accepted):
+        for a, shape in ((chain, (n_steps,) + lead + (w, p)), (lnprob_chain, (n_steps,) + lead + (w,))):
+            if a is not None and (a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape):
+                raise ValueError("stretch_move: chain buffers must be C-contiguous float64 of shape (steps, [B,] W, P) / (steps, [B,] W)")
+        if accepted is not None and (accepted.dtype != np.int64 or accepted.shape != lead + (w,) or not accepted.flags.c_contiguous):
+            raise ValueError("stretch_move: accepted must be a C-contiguous int64 array of shape ([B,] W)")
+
     def stretch_move(self, plan, pos, lnp, order, zz, thr, pick, chain=None, lnprob_chain=None, accepted=None):
         """``mcd_stretch_move``: advance the ensemble by ``len(order)`` stretch-move steps with the half-step loop inside
         the library.  ``plan``: dict with ``col_source`` (int32 [K]), ``col_const``, ``col_factor`` (float64 [K]), ``lo``,
@@ -391,25 +435,35 @@ class Catalog(object):
         if pos.shape != lead + (w, p) or lnp.shape != lead + (w,) or order.shape != (n_steps,) + lead + (w,) or \
                 zz.shape != half_shape or thr.shape != half_shape or pick.shape != half_shape:
             raise ValueError("stretch_move: inconsistent array shapes")
-        cols = [np.ascontiguousarray(plan["col_source"], dtype=np.int32), _f64(plan["col_const"]), _f64(plan["col_factor"]),
-                _f64(plan["lo"]), _f64(plan["hi"])]
-        if cols[0].size != self.k or cols[1].size != self.k or cols[2].size != self.k or cols[3].size != p or cols[4].size != p:
-            raise ValueError("stretch_move: plan does not match the catalogue / the number of free parameters")
-        d = StretchDesc()
-        d.n_walkers, d.n_dim, d.k, d.n_bins = w, p, self.k, n_bins
-        d.col_source = cols[0].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
-        d.col_const, d.col_factor, d.lo, d.hi = (_ptr(c) for c in cols[1:])
-        d.fixed_ok = 1 if plan.get("fixed_ok", True) else 0
-        for a, shape in ((chain, (n_steps,) + lead + (w, p)), (lnprob_chain, (n_steps,) + lead + (w,))):
-            if a is not None and (a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape):
-                raise ValueError("stretch_move: chain buffers must be C-contiguous float64 of shape (steps, [B,] W, P) / (steps, [B,] W)")
-        if accepted is not None and (accepted.dtype != np.int64 or accepted.shape != lead + (w,) or not accepted.flags.c_contiguous):
-            raise ValueError("stretch_move: accepted must be a C-contiguous int64 array of shape ([B,] W)")
+        d, _keep = self._stretch_desc(plan, w, p, n_bins)
+        self._stretch_outputs(n_steps, lead, w, p, chain, lnprob_chain, accepted)
         rc = self.lib.mcd_stretch_move(self.handle, ctypes.byref(d), n_steps, _ptr(pos), _ptr(lnp),
                                        order.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(zz), _ptr(thr),
                                        pick.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(chain), _ptr(lnprob_chain),
                                        accepted.ctypes.data_as(_c_int64_p) if accepted is not None else None)
         _check(self.lib, rc, "mcd_stretch_move")
+        self._walkers = w // 2
+
+    def stretch_move_seeded(self, plan, pos, lnp, seed, step0, n_steps, chain=None, lnprob_chain=None, accepted=None):
+        """``mcd_stretch_move_seeded``: the same block with its random numbers generated inside the library from the
+        counter-based generator of csrc/mcd_rng.h -- steps ``step0 .. step0 + n_steps - 1`` of the chain that ``seed`` names.
+        ``chain_numbers(seed, step0, n_steps, ...)`` returns the numbers those steps use."""
+        self._alive()
+        binned = pos.ndim == 3
+        lead = pos.shape[:1] if binned else ()
+        n_bins = pos.shape[0] if binned else 1
+        w, p = pos.shape[-2], pos.shape[-1]
+        for a in (pos, lnp):
+            if a.dtype != np.float64 or not a.flags.c_contiguous:
+                raise ValueError("stretch_move_seeded needs C-contiguous float64 arrays")
+        if lnp.shape != lead + (w,) or n_steps < 0 or step0 < 0:
+            raise ValueError("stretch_move_seeded: inconsistent array shapes")
+        d, _keep = self._stretch_desc(plan, w, p, n_bins)
+        self._stretch_outputs(n_steps, lead, w, p, chain, lnprob_chain, accepted)
+        rc = self.lib.mcd_stretch_move_seeded(self.handle, ctypes.byref(d), n_steps, _ptr(pos), _ptr(lnp),
+                                              int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0), _ptr(chain), _ptr(lnprob_chain),
+                                              accepted.ctypes.data_as(_c_int64_p) if accepted is not None else None)
+        _check(self.lib, rc, "mcd_stretch_move_seeded")
         self._walkers = w // 2
 
     @property

@@ -30,15 +30,35 @@ class BinnedSampler(object):
 
     N_STREAMS = 8          # part of the definition of the random stream (2: 334, 4: 313, 8: 297 us per step at 55 x 512)
 
-    def __init__(self, n_bins, nwalkers, ndim, log_prob_fn, a=2.0, seed=None, block_fn=None):
+    def __init__(self, n_bins, nwalkers, ndim, log_prob_fn, a=2.0, seed=None, block_fn=None, rng="host", seeded_block_fn=None):
+        """``rng``: where the move's random numbers come from.
+
+        ``"host"``: NumPy's Mersenne twister on the host, as emcee draws (B x W numbers per step cross PCIe: the draws, not
+        the device, bound the rate -- 3400 steps/s at 55 bins x 512 walkers against 6000 of device time).
+
+        ``"device"``: the counter-based generator of csrc/mcd_rng.h (Philox4x64-10): every number is a function of (seed,
+        step, half step, bin, walker) alone.  ``seeded_block_fn`` (``Runner._stretch_block_seeded``) runs whole blocks with
+        the numbers generated inside the step kernel; without it (expression priors) the NumPy loop below takes the SAME
+        numbers from ``_native.chain_numbers`` -- one chain whichever way it is run, and however it is cut into blocks."""
         if nwalkers % 2 or nwalkers < 2 * ndim:
             raise ValueError("need an even number of walkers, at least twice the dimension")
+        if rng not in ("host", "device"):
+            raise ValueError("rng must be 'host' or 'device'")
+        if rng == "device" and float(a) != 2.0:
+            raise ValueError("rng='device' implements the stretch move with a = 2 (emcee's default)")
+        self.rng = rng
+        self.seeded_block_fn = seeded_block_fn
         self.n_bins, self.nwalkers, self.ndim = int(n_bins), int(nwalkers), int(ndim)
         self.log_prob_fn = log_prob_fn
         self.block_fn = block_fn
         self.block_steps = 64                     # steps whose random numbers are drawn together (defines the stream)
         self.a = float(a)
         self._random = np.random.RandomState(seed)
+        # rng="device": the 64-bit name of the chain (no seed: from NumPy's global generator, which the reference seeds at
+        # analysis/runner.py:59 -- `np.random.seed` before the run makes it reproducible, as with emcee)
+        self.seed64 = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else \
+            (int(np.random.randint(0, 2 ** 32)) << 32) | int(np.random.randint(0, 2 ** 32))
+        self.device_block_steps = 256             # rng="device": steps per library call (NOT part of the stream's definition)
         # the steps of a block are drawn by N_STREAMS generators seeded from the master (see run_mcmc: draw)
         self._streams = [np.random.RandomState(int(s)) for s in self._random.randint(0, 2 ** 31 - 1, size=self.N_STREAMS)]
         from concurrent.futures import ThreadPoolExecutor
@@ -134,16 +154,32 @@ class BinnedSampler(object):
         done = 0
         # (blocks of very many ensembles are kept below ~8 M walker-steps: 200 MB of numbers in, 340 MB of rows out)
         chunk = max(1, min(int(self.block_steps), (1 << 23) // (B * W)))
+        device_rng = self.rng == "device"
+        if device_rng:
+            chunk = max(1, min(int(self.device_block_steps), (1 << 23) // (B * W)))
+            if self.seeded_block_fn is None:
+                from .. import _native as native
+
+                def draw(n):                                 # noqa: F811 -- the same numbers the step kernel generates
+                    return native.chain_numbers(self.seed64, self.iteration, n, B, W, P)
         pending = None
         while done < nsteps:
             n = min(chunk, nsteps - done)
+            if device_rng and self.seeded_block_fn is not None:
+                it = self.iteration
+                accepted = np.zeros((B, W), dtype=np.int64)
+                self.seeded_block_fn(pos, lnp, self.seed64, it, n, self._chain[it:it + n], self._lnprob[it:it + n], accepted)
+                self._accepted += accepted
+                self.iteration += n
+                done += n
+                continue
             order_b, zz_b, thr_b, pick_b = pending.result() if pending is not None else draw(n)
             pending = None
-            if self.block_fn is not None and done + n < nsteps:
+            if self.block_fn is not None and done + n < nsteps and not device_rng:
                 # the next block's numbers are drawn while the library call of this block waits for the device
                 pending = self._lookahead.submit(draw, min(chunk, nsteps - done - n))
             it = self.iteration
-            if self.block_fn is not None:
+            if self.block_fn is not None and not device_rng:
                 accepted = np.zeros((B, W), dtype=np.int64)
                 try:
                     self.block_fn(pos, lnp, order_b, zz_b, thr_b, pick_b, self._chain[it:it + n], self._lnprob[it:it + n], accepted)
@@ -251,8 +287,11 @@ class BinnedConstantFit(ConstantFit):
     def lnlike(self, values):
         return float(self.lnlike_total(np.asarray(values, dtype=np.float64).reshape(1, -1))[0])
 
-    def __call__(self, n_walkers=100, n_steps=100, pos=None, seed=None, **kwargs):
-        """Run the B ensembles in lockstep; returns a ``BinnedSampler`` (``.chain``: (B, W, steps, P))."""
+    RNG = "device"                 # where BinnedSampler's random numbers come from ("host": NumPy's generator, as emcee)
+
+    def __call__(self, n_walkers=100, n_steps=100, pos=None, seed=None, rng=None, **kwargs):
+        """Run the B ensembles in lockstep; returns a ``BinnedSampler`` (``.chain``: (B, W, steps, P)).  ``rng``: see
+        ``BinnedSampler`` (default: the class attribute ``RNG``)."""
         if kwargs.get("n_threads", 1) != 1:
             raise ValueError("n_threads > 1 is not supported by the GPU backend.")
         if pos is None:
@@ -262,8 +301,10 @@ class BinnedConstantFit(ConstantFit):
         if not np.all(np.isfinite(lp)):
             raise ValueError("Invalid initial guesses for {0} walker(s).".format(int(np.sum(~np.isfinite(lp)))))
         # box priors: whole blocks of steps inside the library (mcd_stretch_move with n_bins = B, Runner._stretch_block)
+        native_ok = self._plan().simple and self.n_bins > 1
         sampler = BinnedSampler(self.n_bins, n_walkers, self.n_fitted_parameters, self.lnprob_batch, seed=seed,
-                                block_fn=self._stretch_block if self._plan().simple and self.n_bins > 1 else None)
+                                block_fn=self._stretch_block if native_ok else None, rng=rng or self.RNG,
+                                seeded_block_fn=self._stretch_block_seeded if native_ok else None)
         sampler.run_mcmc(pos, n_steps)
         return sampler
 

@@ -414,9 +414,16 @@ class Runner(object):
         logger.info("MCMC driver: built-in stretch move (emcee's default move), %s",
                     "blocks of steps inside the library, ensemble resident on the device" if resident
                     else "Python loop around lnprob_batch (" + why_not + ")")
+        if self.RNG not in ("host", "device"):
+            raise ValueError("Runner.RNG must be 'host' or 'device'")
         return EnsembleSampler(n_walkers, self.n_fitted_parameters, self.lnprob_batch, vectorize=True, seed=seed,
-                               block_fn=self._stretch_block if resident else None)
+                               block_fn=self._stretch_block if resident else None, rng=self.RNG,
+                               seeded_block_fn=self._stretch_block_seeded if resident else None)
 
+    # the built-in move's random numbers: "host" -- NumPy's Mersenne twister, drawn on the host as emcee does; "device" --
+    # the counter-based generator of csrc/mcd_rng.h inside the step kernel (a function of (seed, step, walker): no numbers
+    # cross PCIe, the chain does not depend on how it is cut into blocks)
+    RNG = "host"
     NATIVE_STRETCH = True          # sub-classes whose posterior is not ONE un-binned catalogue switch this off
 
     def _stretch_plan(self):
@@ -442,6 +449,18 @@ class Runner(object):
                "hi": plan.hi[plan.free_idx].copy(), "fixed_ok": fixed_ok}
         self._stretch_cache = (plan, out)
         return out
+
+    def _stretch_block_seeded(self, pos, lnp, seed, step0, n_steps, chain, lnprob_chain, accepted):
+        """One block of steps with the random numbers generated inside the library (``_native.Catalog.stretch_move_seeded``)."""
+        plan = self._plan()
+        if not plan.simple:
+            raise RuntimeError("the parameter configuration changed to one with expression priors / constraints during a run")
+        if self._context is not None and getattr(self._context, "n_ranks", 1) > 1:
+            self._check_ranks_agree(pos)
+        cat = self._catalog
+        if cat is None or plan.catalog_key != self._catalog_key:
+            cat = self._ensure_catalog()
+        cat.stretch_move_seeded(self._stretch_plan(), pos, lnp, seed, step0, n_steps, chain, lnprob_chain, accepted)
 
     def _stretch_block(self, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted):
         """One block of stretch-move steps inside the library (``_native.Catalog.stretch_move``)."""

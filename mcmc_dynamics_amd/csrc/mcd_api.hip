@@ -27,6 +27,7 @@
 #include "mcd_internal.h"
 #include "mcd_guard.h"
 #include "mcd_math.h"
+#include "mcd_rng.h"
 #include "mcd_stretch.h"
 
 namespace {
@@ -625,10 +626,6 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
                 lane_partials = w.d_partials2;
                 w.lane1_used = true;
             }
-            if (coll && w.comm_pending[w.buf]) {
-                MCD_HIP(hipStreamWaitEvent(lane_stream, w.ev_comm[w.buf], 0));
-                w.comm_pending[w.buf] = false;
-            }
         } else {
             w.buf = 0;
         }
@@ -662,6 +659,14 @@ int enqueue(mcd_catalog* cat, bool pipelined) {
         const int bgk = mcd::bg_kind(cat->model);
         const double* pset_const =
             (w.fast && (bgk == mcd::BG_FIXED || bgk == mcd::BG_FIXED_DENSITY)) ? sh.d_pset_const : nullptr;
+        // With a collective this step may only overwrite its result buffer once the all-reduce that last used it has
+        // finished.  Only the REDUCTION writes that buffer (the main kernel's re-run signal travels in the partial sums
+        // here), so the wait sits in front of it, not in front of the main kernel: with two lanes a lane reuses the buffer
+        // of its own previous step, and the all-reduce of that step would otherwise be on the lane's critical path.
+        if (coll && w.comm_pending[w.buf]) {
+            MCD_HIP(hipStreamWaitEvent(lane_stream, w.ev_comm[w.buf], 0));
+            w.comm_pending[w.buf] = false;
+        }
         {
             const int64_t n_slots = mcd::partial_slots(shape, w.n_chunks, W);
             MCD_HIP(mcd::launch_reduce(lane_stream, lane_partials, w.d_offsets, cat->n_psets, n_slots,
@@ -837,9 +842,12 @@ void big_copy(void* dst, const void* src, size_t bytes) {
     (void)started;
 }
 
+// `seed` != nullptr: a seeded block (mcd_stretch_move_seeded) -- order / zz / thr / pick are null, the step kernel generates
+// the numbers of absolute steps step0 .. step0 + n_steps - 1 itself (mcd_rng.h)
 int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
                          const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
-                         double* lnprob_chain, int64_t* accepted, bool* done) {
+                         double* lnprob_chain, int64_t* accepted, bool* done, const uint64_t* seed = nullptr,
+                         int64_t step0 = 0) {
     *done = false;
     mcd_ctx* ctx = cat->ctx;
     if (int urc = ctx_usable(ctx)) return urc;
@@ -853,7 +861,9 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     {
         mcd::StretchDevice probe;
         probe.n_bins = B; probe.n_walkers = W; probe.n_dim = P; probe.k = K;
+        probe.force_general = cat->device_chain == 2;
         if (!mcd::stretch_step_handles(probe)) return MCD_OK;
+        if (seed && !mcd::stretch_step_fuses(probe)) return MCD_OK;          // (only the in-LDS step kernel generates numbers)
     }
     Shard& sh = cat->shards[0];
     const DeviceSlot& slot = ctx->slots[sh.slot];
@@ -879,9 +889,12 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     const size_t state_end = off;
     const size_t o_src = take((size_t)K * 4), o_const = take((size_t)K * 8), o_fac = take((size_t)K * 8);
     const size_t o_lo = take((size_t)P * 8), o_hi = take((size_t)P * 8);
-    const size_t o_order = take((size_t)n_steps * BW * 4), o_zz = take((size_t)n_steps * BW * 8);
-    const size_t o_thr = take((size_t)n_steps * BW * 8), o_pick = take((size_t)n_steps * BW * 4);
+    const bool seeded = seed != nullptr;
+    const size_t n_in = seeded ? 0 : (size_t)n_steps;                    // seeded blocks upload no numbers
+    const size_t o_order = take(n_in * BW * 4), o_zz = take(n_in * BW * 8);
+    const size_t o_thr = take(n_in * BW * 8), o_pick = take(n_in * BW * 4);
     const size_t input_end = off;
+    const size_t o_order_scratch = take(seeded ? BW * 4 : 0), o_thr_scratch = take(seeded ? BW * 8 : 0);
     const size_t o_prop = take(Bh * P * 8), o_ok = take(Bh), o_nok = take((size_t)2 * B * 4), o_ranges = take((size_t)2 * B * 10 * 8);
     const size_t o_chain = take(chain ? (size_t)n_steps * BW * P * 8 : 0);
     const size_t o_lnpc = take(lnprob_chain ? (size_t)n_steps * BW * 8 : 0);
@@ -926,7 +939,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     // Blocks that move tens of MB (binned catalogues: the random numbers of 64 steps of 55 x 512 walkers are 40 MB, their
     // chain rows 70 MB -- a third of the block's device time in copies) are cut into parts: the host copies and the PCIe
     // transfers of one part overlap the device work of another (copies on the second stream, joined by events).
-    const size_t moved = (size_t)n_steps * BW * (24 + (chain ? (size_t)P * 8 : 0) + (lnprob_chain ? 8 : 0));
+    const size_t moved = (size_t)n_steps * BW * ((seeded ? 0 : 24) + (chain ? (size_t)P * 8 : 0) + (lnprob_chain ? 8 : 0));
     size_t part_threshold = (size_t)16 << 20;
     if (const char* e = std::getenv("MCD_CHAIN_PART_BYTES")) part_threshold = (size_t)std::strtoull(e, nullptr, 10);   // testing aid
     // (what stays exposed is the first part's numbers going in and the last part's rows coming out: 1 / n_parts of the copies.
@@ -936,6 +949,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     const int64_t n_parts = moved >= part_threshold ? std::min<int64_t>(max_parts, n_steps) : 1;
     auto part_begin = [&](int64_t k) { return n_steps * k / n_parts; };
     auto copy_in = [&](int64_t i0, int64_t i1) {              // the random numbers of steps i0 .. i1: user -> pinned
+        if (seeded) return;
         const size_t at = (size_t)i0 * BW, n = (size_t)(i1 - i0) * BW;
         big_copy(a.h + o_order + at * 4, order + at, n * 4);
         big_copy(a.h + o_zz + at * 8, zz + at, n * 8);
@@ -969,6 +983,11 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     sd.pos = (double*)(a.d + o_pos); sd.lnp = (double*)(a.d + o_lnp); sd.accepted = (long long*)(a.d + o_acc);
     sd.order = (const int32_t*)(a.d + o_order); sd.zz = (const double*)(a.d + o_zz); sd.thr = (const double*)(a.d + o_thr);
     sd.pick = (const int32_t*)(a.d + o_pick);
+    if (seeded) {
+        sd.order = nullptr; sd.zz = nullptr; sd.thr = nullptr; sd.pick = nullptr;
+        sd.seeded = 1; sd.seed = *seed; sd.step0 = step0;
+        sd.order_scratch = (int32_t*)(a.d + o_order_scratch); sd.thr_scratch = (double*)(a.d + o_thr_scratch);
+    }
     sd.chain = chain ? (double*)(a.d + o_chain) : nullptr;
     sd.lnprob_chain = lnprob_chain ? (double*)(a.d + o_lnpc) : nullptr;
     sd.proposal = (double*)(a.d + o_prop); sd.ok = (uint8_t*)(a.d + o_ok); sd.meta = (int32_t*)(a.d + o_meta);
@@ -1100,13 +1119,15 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         for (int64_t k = 0; k < n_parts; ++k) {
             const int64_t i0 = part_begin(k), i1 = part_begin(k + 1);
             const size_t at = (size_t)i0 * BW, n = (size_t)(i1 - i0) * BW;
-            copy_in(i0, i1);
-            MCD_HIP(hipMemcpyAsync(a.d + o_order + at * 4, a.h + o_order + at * 4, n * 4, hipMemcpyHostToDevice, slot.comm_stream));
-            MCD_HIP(hipMemcpyAsync(a.d + o_zz + at * 8, a.h + o_zz + at * 8, n * 8, hipMemcpyHostToDevice, slot.comm_stream));
-            MCD_HIP(hipMemcpyAsync(a.d + o_thr + at * 8, a.h + o_thr + at * 8, n * 8, hipMemcpyHostToDevice, slot.comm_stream));
-            MCD_HIP(hipMemcpyAsync(a.d + o_pick + at * 4, a.h + o_pick + at * 4, n * 4, hipMemcpyHostToDevice, slot.comm_stream));
-            MCD_HIP(hipEventRecord(ev_in[k], slot.comm_stream));
-            MCD_HIP(hipStreamWaitEvent(slot.stream, ev_in[k], 0));
+            if (!seeded) {
+                copy_in(i0, i1);
+                MCD_HIP(hipMemcpyAsync(a.d + o_order + at * 4, a.h + o_order + at * 4, n * 4, hipMemcpyHostToDevice, slot.comm_stream));
+                MCD_HIP(hipMemcpyAsync(a.d + o_zz + at * 8, a.h + o_zz + at * 8, n * 8, hipMemcpyHostToDevice, slot.comm_stream));
+                MCD_HIP(hipMemcpyAsync(a.d + o_thr + at * 8, a.h + o_thr + at * 8, n * 8, hipMemcpyHostToDevice, slot.comm_stream));
+                MCD_HIP(hipMemcpyAsync(a.d + o_pick + at * 4, a.h + o_pick + at * 4, n * 4, hipMemcpyHostToDevice, slot.comm_stream));
+                MCD_HIP(hipEventRecord(ev_in[k], slot.comm_stream));
+                MCD_HIP(hipStreamWaitEvent(slot.stream, ev_in[k], 0));
+            }
             rc = enqueue_steps(i0, i1, k > 0 ? ev_rows[k - 1] : nullptr);
             if (rc != MCD_OK) return rc;
             if (k > 0) {
@@ -1614,49 +1635,100 @@ int mcd_kde_background(mcd_ctx* ctx, int64_t n_comp, const double* comp, int64_t
     } catch (...) { return on_exception("mcd_kde_background"); }
 }
 
-int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
-                     const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
-                     double* lnprob_chain, int64_t* accepted) {
-    try {
-    if (!cat || !d || !pos || !lnp || !order || !zz || !thr || !pick) return fail(MCD_ERR_INVALID, "mcd_stretch_move: null argument");
+namespace {
+// common part of mcd_stretch_move / mcd_stretch_move_seeded: argument checks, the resident block, else the host-driven one
+int run_stretch(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
+                const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
+                double* lnprob_chain, int64_t* accepted, const uint64_t* seed, int64_t step0) {
+    const char* who = seed ? "mcd_stretch_move_seeded" : "mcd_stretch_move";
+    if (!cat || !d || !pos || !lnp) return fail(MCD_ERR_INVALID, std::string(who) + ": null argument");
+    if (!seed && (!order || !zz || !thr || !pick)) return fail(MCD_ERR_INVALID, std::string(who) + ": null argument");
     const int64_t B = d->n_bins > 1 ? d->n_bins : 1;
     if (B != cat->n_psets)
-        return fail(MCD_ERR_INVALID, "mcd_stretch_move: desc->n_bins must equal the catalogue's number of parameter sets (radial bins)");
-    if (d->k != cat->k) return fail(MCD_ERR_INVALID, "mcd_stretch_move: descriptor has the wrong number of kernel columns");
-    if (d->n_walkers <= 0 || (d->n_walkers & 1) || d->n_dim <= 0 || n_steps < 0)
-        return fail(MCD_ERR_INVALID, "mcd_stretch_move: n_walkers must be positive and even, n_dim positive");
-    if (!d->col_source || !d->col_const || !d->col_factor || !d->lo || !d->hi) return fail(MCD_ERR_INVALID, "mcd_stretch_move: null descriptor array");
+        return fail(MCD_ERR_INVALID, std::string(who) + ": desc->n_bins must equal the catalogue's number of parameter sets (radial bins)");
+    if (d->k != cat->k) return fail(MCD_ERR_INVALID, std::string(who) + ": descriptor has the wrong number of kernel columns");
+    if (d->n_walkers <= 0 || (d->n_walkers & 1) || d->n_dim <= 0 || n_steps < 0 || step0 < 0)
+        return fail(MCD_ERR_INVALID, std::string(who) + ": n_walkers must be positive and even, n_dim positive, steps non-negative");
+    if (!d->col_source || !d->col_const || !d->col_factor || !d->lo || !d->hi) return fail(MCD_ERR_INVALID, std::string(who) + ": null descriptor array");
     for (int c = 0; c < d->k; ++c)
-        if (d->col_source[c] >= d->n_dim) return fail(MCD_ERR_INVALID, "mcd_stretch_move: col_source outside the free parameters");
+        if (d->col_source[c] >= d->n_dim) return fail(MCD_ERR_INVALID, std::string(who) + ": col_source outside the free parameters");
     const int64_t W = d->n_walkers, half = W / 2;
-    // (range checks as min / max reductions: branch-free, vectorised -- a binned block holds millions of indices)
-    auto within = [](const int32_t* a, int64_t n, int64_t bound) {
-        int32_t lo = 0, hi = 0;
-        for (int64_t i = 0; i < n; ++i) { lo = a[i] < lo ? a[i] : lo; hi = a[i] > hi ? a[i] : hi; }
-        return lo >= 0 && (int64_t)hi < bound;
-    };
-    if (!within(order, n_steps * B * W, W)) return fail(MCD_ERR_INVALID, "mcd_stretch_move: order holds an index outside 0..W-1");
-    if (!within(pick, n_steps * B * W, half)) return fail(MCD_ERR_INVALID, "mcd_stretch_move: pick holds an index outside the half ensemble");
+    if (!seed) {
+        // (range checks as min / max reductions: branch-free, vectorised -- a binned block holds millions of indices)
+        auto within = [](const int32_t* a, int64_t n, int64_t bound) {
+            int32_t lo = 0, hi = 0;
+            for (int64_t i = 0; i < n; ++i) { lo = a[i] < lo ? a[i] : lo; hi = a[i] > hi ? a[i] : hi; }
+            return lo >= 0 && (int64_t)hi < bound;
+        };
+        if (!within(order, n_steps * B * W, W)) return fail(MCD_ERR_INVALID, "mcd_stretch_move: order holds an index outside 0..W-1");
+        if (!within(pick, n_steps * B * W, half)) return fail(MCD_ERR_INVALID, "mcd_stretch_move: pick holds an index outside the half ensemble");
+    }
     mcd::StretchDesc sd;
     sd.n_bins = B;
     sd.n_walkers = W; sd.n_dim = d->n_dim; sd.k = d->k; sd.col_source = d->col_source; sd.col_const = d->col_const;
     sd.col_factor = d->col_factor; sd.lo = d->lo; sd.hi = d->hi; sd.fixed_ok = d->fixed_ok;
     bool done = false;
-    const int dev_rc = stretch_block_device(cat, d, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted, &done);
+    const int dev_rc = stretch_block_device(cat, d, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted, &done,
+                                            seed, step0);
     if (dev_rc != MCD_OK) return dev_rc;
     if (done) return MCD_OK;
     ++cat->chain_host_blocks;
+    // host-driven block.  Seeded: the same numbers, from the same functions compiled for the host (mcd_rng.h) -- one step at
+    // a time, so that a block of any length needs the numbers of one step only
+    std::vector<int32_t> g_order, g_pick;
+    std::vector<double> g_zz, g_thr, g_keys;
+    std::vector<std::pair<double, int32_t>> sorter;
     int eval_rc = MCD_OK;
-    const int rc = mcd::stretch_block(sd, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted,
-                                      [&](const double* table, int64_t n, double* out) {
-                                          eval_rc = mcd_loglike_batch(cat, n, d->k, table, out);
-                                          return eval_rc;
-                                      });
+    auto eval = [&](const double* table, int64_t n, double* out) {
+        eval_rc = mcd_loglike_batch(cat, n, d->k, table, out);
+        return eval_rc;
+    };
+    int rc = mcd::STRETCH_OK;
+    if (!seed) {
+        rc = mcd::stretch_block(sd, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted, eval);
+    } else {
+        g_order.resize((size_t)B * W); g_pick.resize((size_t)2 * B * half); g_zz.resize((size_t)2 * B * half); g_thr.resize((size_t)2 * B * half);
+        for (int64_t i = 0; i < n_steps && rc == mcd::STRETCH_OK; ++i) {
+            mcd::chain_numbers_of_step(*seed, step0 + i, B, W, d->n_dim, g_order.data(), g_zz.data(), g_thr.data(), g_pick.data(), sorter);
+            rc = mcd::stretch_block(sd, 1, pos, lnp, g_order.data(), g_zz.data(), g_thr.data(), g_pick.data(),
+                                    chain ? chain + (size_t)i * B * W * d->n_dim : nullptr,
+                                    lnprob_chain ? lnprob_chain + (size_t)i * B * W : nullptr, accepted, eval);
+        }
+    }
     if (rc == mcd::STRETCH_EVAL_FAILED) return eval_rc;                  // message already set by mcd_loglike_batch
-    if (rc == mcd::STRETCH_NAN) return fail(MCD_ERR_NONFINITE, "mcd_stretch_move: the log-likelihood returned NaN");
-    if (rc != mcd::STRETCH_OK) return fail(MCD_ERR_INVALID, "mcd_stretch_move: bad arguments");
+    if (rc == mcd::STRETCH_NAN) return fail(MCD_ERR_NONFINITE, std::string(who) + ": the log-likelihood returned NaN");
+    if (rc != mcd::STRETCH_OK) return fail(MCD_ERR_INVALID, std::string(who) + ": bad arguments");
     return MCD_OK;
+}
+}  // namespace
+
+int mcd_stretch_move(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
+                     const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
+                     double* lnprob_chain, int64_t* accepted) {
+    try {
+    return run_stretch(cat, d, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted, nullptr, 0);
     } catch (...) { return on_exception("mcd_stretch_move"); }
+}
+
+int mcd_stretch_move_seeded(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
+                            uint64_t seed, int64_t step0, double* chain, double* lnprob_chain, int64_t* accepted) {
+    try {
+    return run_stretch(cat, d, n_steps, pos, lnp, nullptr, nullptr, nullptr, nullptr, chain, lnprob_chain, accepted, &seed, step0);
+    } catch (...) { return on_exception("mcd_stretch_move_seeded"); }
+}
+
+int mcd_chain_numbers(uint64_t seed, int64_t step0, int64_t n_steps, int64_t n_bins, int64_t n_walkers, int32_t n_dim,
+                      int32_t* order, double* zz, double* thr, int32_t* pick) {
+    try {
+    if (!order || !zz || !thr || !pick || n_steps < 0 || step0 < 0 || n_walkers <= 0 || (n_walkers & 1) || n_dim <= 0)
+        return fail(MCD_ERR_INVALID, "mcd_chain_numbers: bad arguments");
+    const int64_t B = n_bins > 1 ? n_bins : 1, W = n_walkers, half = W / 2;
+    std::vector<std::pair<double, int32_t>> sorter;
+    for (int64_t i = 0; i < n_steps; ++i)
+        mcd::chain_numbers_of_step(seed, step0 + i, B, W, n_dim, order + (size_t)i * B * W, zz + (size_t)i * 2 * B * half,
+                                   thr + (size_t)i * 2 * B * half, pick + (size_t)i * 2 * B * half, sorter);
+    return MCD_OK;
+    } catch (...) { return on_exception("mcd_chain_numbers"); }
 }
 
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {

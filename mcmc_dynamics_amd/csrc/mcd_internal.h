@@ -83,6 +83,14 @@ struct StretchDevice {
     long long launch_index = 0;
 #endif
     int32_t force_general = 0;             // testing aid (option "device_chain" = 2): the general step kernel for any size
+    // seeded blocks (mcd_stretch_move_seeded): the block's random numbers are generated where they are used (mcd_rng.h) --
+    // order / zz / thr / pick above are null; the step kernel keeps the current step's split and the pending acceptance
+    // thresholds in the two scratch arrays
+    int32_t seeded = 0;
+    uint64_t seed = 0;
+    int64_t step0 = 0;                     // absolute index of the block's first step (the counter of the generator)
+    int32_t* order_scratch = nullptr;      // [B][W]
+    double* thr_scratch = nullptr;         // [2][B][W/2] by half-step parity
     // fused reduction (launches whose partial sums are few, kFusedReduceSlots): the step kernel adds up the main kernel's
     // partial sums itself instead of reading the sums a reduction kernel left in `ll` -- one kernel less per half step
     int32_t fused = 0;

@@ -22,6 +22,7 @@
 #include "mcd_math.h"
 #include "mcd_prep.h"
 #include "mcd_reduce.h"
+#include "mcd_rng.h"
 
 namespace mcd {
 
@@ -239,6 +240,8 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
     __shared__ double s_lo[kMaxCols], s_hi[kMaxCols], s_const[kMaxCols], s_factor[kMaxCols];
     __shared__ int s_source[kMaxCols];
     __shared__ double s_rows[kStepBlock][kMaxCols + 1];        // (+1: rows of different threads start in different banks)
+    __shared__ double s_keys[2 * kStepBlock];                  // seeded blocks: the step's ordering keys and the split they give
+    __shared__ int s_order[2 * kStepBlock];
     double* const s_pos = s_dynamic;
     double* const s_lnp = s_dynamic + W * P;
     int* const s_second = reinterpret_cast<int*>(s_lnp + W);
@@ -276,8 +279,13 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
         if (active) {
             ok_prev = ok_b[j] != 0;
             if constexpr (!kFused) ll_j = ll_b[j];
-            w_acc = d.order[(acc_step * B + b) * W + (acc_h == 0 ? 0 : half) + j];
-            thr_j = d.thr[((acc_step * 2 + acc_h) * B + b) * half + j];
+            if (d.seeded) {
+                w_acc = d.order_scratch[b * W + (acc_h == 0 ? 0 : half) + j];
+                thr_j = d.thr_scratch[((int64_t)acc_h * B + b) * half + j];
+            } else {
+                w_acc = d.order[(acc_step * B + b) * W + (acc_h == 0 ? 0 : half) + j];
+                thr_j = d.thr[((acc_step * 2 + acc_h) * B + b) * half + j];
+            }
 #pragma unroll
             for (int c = 0; c < kMaxCols; ++c) prev[c] = c < P ? proposal_b[j * P + c] : 0.0;
         }
@@ -293,11 +301,15 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
     }
     int w_s = 0, pick_j = 0;
     double z_j = 0.0;
-    if (do_prop && active) {
+    if (do_prop && active && !d.seeded) {
         w_s = d.order[(prop_step * B + b) * W + (prop_h == 0 ? 0 : half) + j];
         s_second[j] = d.order[(prop_step * B + b) * W + (prop_h == 0 ? half : 0) + j];
         pick_j = d.pick[((prop_step * 2 + prop_h) * B + b) * half + j];
         z_j = d.zz[((prop_step * 2 + prop_h) * B + b) * half + j];
+    }
+    if (do_prop && active && d.seeded && prop_h == 1) {        // second half step: the split this step's first launch left
+        w_s = d.order_scratch[b * W + half + j];
+        s_second[j] = d.order_scratch[b * W + j];
     }
     if (do_prop && j < kMaxCols) {
         s_lo[j] = j < P ? d.lo[j] : 0.0;
@@ -358,6 +370,35 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
     }
     MCD_STAMP(2);
     if (!do_prop) return;
+    if (d.seeded) {
+        // ---- this half step's random numbers, generated here (mcd_rng.h): a function of (seed, step, half step, ensemble,
+        // walker / slot) alone.  First half step of a step: the split of the ensemble = argsort of one key per walker (ties by
+        // walker index), by counting -- every thread ranks its (at most two) walkers against all keys in LDS.
+        const int64_t step = d.step0 + prop_step;
+        if (prop_h == 0) {
+            for (int w = j; w < W; w += kStepBlock) s_keys[w] = chain_order_key(d.seed, step, b, w);
+            __syncthreads();
+            for (int w = j; w < W; w += kStepBlock) {
+                const double kw = s_keys[w];
+                int rank = 0;
+                for (int v = 0; v < W; ++v) {
+                    const double kv = s_keys[v];
+                    rank += (kv < kw || (kv == kw && v < w)) ? 1 : 0;
+                }
+                s_order[rank] = w;
+            }
+            __syncthreads();
+            for (int x = j; x < W; x += kStepBlock) d.order_scratch[b * W + x] = s_order[x];
+            if (active) { w_s = s_order[j]; s_second[j] = s_order[half + j]; }
+        }
+        if (active) {
+            const ChainDraw cd = chain_draw(d.seed, step, prop_h, b, j, half, P);
+            z_j = cd.z;
+            pick_j = cd.pick;
+            d.thr_scratch[((int64_t)prop_h * B + b) * half + j] = cd.thr;
+        }
+        __syncthreads();                                       // (s_second is complete before the partner look-ups)
+    }
     // ---- propose ----
     bool good = false;
     double mine_prop[kMaxCols];
@@ -488,7 +529,7 @@ hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t ac
             hipLaunchKernelGGL((stretch_step_small_kernel<C, BINNED, false>), dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, \
                                s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);                                       \
     } while (0)
-    if (d.fused && !small) return hipErrorInvalidValue;
+    if ((d.fused || d.seeded) && !small) return hipErrorInvalidValue;
     const bool binned = d.n_bins > 1;
     if (small && cols <= 4) { if (binned) MCD_LAUNCH_SMALL(4, true); else MCD_LAUNCH_SMALL(4, false); }
     else if (small && cols <= 8) { if (binned) MCD_LAUNCH_SMALL(8, true); else MCD_LAUNCH_SMALL(8, false); }

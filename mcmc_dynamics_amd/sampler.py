@@ -36,7 +36,20 @@ def _draw_pool():
 
 class EnsembleSampler(object):
 
-    def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, a=2.0, vectorize=False, seed=None, block_fn=None):
+    def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, a=2.0, vectorize=False, seed=None, block_fn=None, rng="host",
+                 seeded_block_fn=None):
+        """``rng="device"``: the move's random numbers come from the counter-based generator of csrc/mcd_rng.h instead of
+        NumPy's Mersenne twister -- a function of (seed, step, half step, walker) alone, generated inside the step kernel by
+        ``seeded_block_fn`` (``Runner._stretch_block_seeded``), or taken from ``_native.chain_numbers`` by the Python loop
+        below when there is none: the same chain either way, and however it is cut into blocks."""
+        if rng not in ("host", "device"):
+            raise ValueError("rng must be 'host' or 'device'")
+        if rng == "device" and float(a) != 2.0:
+            raise ValueError("rng='device' implements the stretch move with a = 2 (emcee's default)")
+        self.rng = rng
+        self.seeded_block_fn = seeded_block_fn
+        self.seed64 = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else \
+            (int(np.random.randint(0, 2 ** 32)) << 32) | int(np.random.randint(0, 2 ** 32))
         if nwalkers < 2 * ndim:
             raise ValueError("The number of walkers must be at least twice the dimension.")   # as emcee
         if nwalkers % 2:
@@ -183,20 +196,40 @@ class EnsembleSampler(object):
         # past the block that was never run.)
         pool = None
         chunk = max(1, int(self.block_steps))
-        if self.block_fn is not None and nsteps > chunk:
+        device_rng = self.rng == "device"
+        if device_rng and self.seeded_block_fn is None:
+            from . import _native as native
+
+            def draw(block):                                 # noqa: F811 -- the same numbers the step kernel generates
+                order_b, zz_b, thr_b, pick_b = native.chain_numbers(self.seed64, self.iteration, block, 1, self.nwalkers,
+                                                                    self.ndim, squeeze=True)
+                return order_b.astype(np.int64), zz_b, thr_b, pick_b
+        if self.block_fn is not None and nsteps > chunk and not device_rng:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(max_workers=1)
         pending = None
         try:
             # (the same partition into blocks with and without block_fn: the two then consume the generator alike)
             first = max(1, min(chunk, int(self.first_block_steps))) if nsteps > chunk else chunk
+            if device_rng:
+                first = chunk                                 # (no draws to hide: equal blocks)
             while done < nsteps:
                 block = min(first if done == 0 else chunk, nsteps - done)
+                if device_rng and self.seeded_block_fn is not None:
+                    it = self.iteration
+                    accepted = np.zeros(self.nwalkers, dtype=np.int64)
+                    self.seeded_block_fn(pos, lnp, self.seed64, it, block, self._chain[it:it + block] if store else None,
+                                         self._lnprob[it:it + block] if store else None, accepted)
+                    self._accepted += accepted
+                    self.iteration += block
+                    self.n_calls += 2 * block
+                    done += block
+                    continue
                 order_b, zz_b, thr_b, pick_b = pending.result() if pending is not None else draw(block)
                 pending = None
                 if pool is not None and done + block < nsteps:
                     pending = pool.submit(draw, min(chunk, nsteps - done - block))
-                if self.block_fn is not None:
+                if self.block_fn is not None and not device_rng:
                     # the same half-step loop, in the library (csrc/mcd_stretch.h): identical numbers, no Python between launches
                     it = self.iteration
                     accepted = np.zeros(self.nwalkers, dtype=np.int64)

@@ -8,6 +8,7 @@
 #include "mcd_chunks.h"
 #include "mcd_guard.h"
 #include "mcd_math.h"
+#include "mcd_rng.h"
 #include "mcd_stretch.h"
 
 using namespace mcd;
@@ -275,4 +276,25 @@ extern "C" int emul_stretch_block(int64_t B, int64_t W, int P, int K, const int3
     d.lo = lo; d.hi = hi; d.fixed_ok = fixed_ok;
     return stretch_block(d, n_steps, pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted,
                          [&](const double* t, int64_t n, double* out) { return eval(t, n, out); });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The chain's counter-based random numbers (csrc/mcd_rng.h), compiled for the host.
+extern "C" void emul_philox(const uint64_t* counter, const uint64_t* key, uint64_t* out) {
+    const Philox4x64 r = philox4x64_10(counter[0], counter[1], counter[2], counter[3], key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+extern "C" void emul_det_log(int64_t n, const double* x, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = det_log(x[i]);
+}
+extern "C" void emul_chain_numbers(uint64_t seed, int64_t step0, int64_t n_steps, int64_t B, int64_t W, int n_dim,
+                                   int32_t* order, double* zz, double* thr, int32_t* pick) {
+    std::vector<std::pair<double, int32_t>> sorter;
+    const int64_t half = W / 2;
+    for (int64_t i = 0; i < n_steps; ++i)
+        chain_numbers_of_step(seed, step0 + i, B, W, n_dim, order + i * B * W, zz + i * 2 * B * half, thr + i * 2 * B * half,
+                              pick + i * 2 * B * half, sorter);
+}
+extern "C" void emul_chain_keys(uint64_t seed, int64_t step, int64_t b, int64_t W, double* out) {
+    for (int64_t w = 0; w < W; ++w) out[w] = chain_order_key(seed, step, b, w);
 }

@@ -23,7 +23,7 @@ def lib():
     global _lib
     if _lib is None:
         deps = [SRC, os.path.join(INC, "mcd_math.h"), os.path.join(INC, "mcd_guard.h"),
-                os.path.join(INC, "mcd_exp_table.h"), os.path.join(INC, "mcd_chunks.h"), os.path.join(INC, "mcd_stretch.h")]
+                os.path.join(INC, "mcd_exp_table.h"), os.path.join(INC, "mcd_chunks.h"), os.path.join(INC, "mcd_stretch.h"), os.path.join(INC, "mcd_rng.h")]
         if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", INC, SRC,
                             "-o", OUT], check=True)
@@ -250,3 +250,47 @@ def f32_domain(cat, params, model, centre=None):
                                ptr(cols["verr"]), ptr(cols["lnlike_bg"]), ptr(cols["pmember"]), ptr(cols["density"]),
                                p.shape[1], p.ctypes.data, p.shape[0], kappa.ctypes.data, reason, 400, rc_, dc_)
     return bool(inside), float(kappa[0]), float(kappa[1]), float(kappa[2]), reason.value.decode()
+
+
+def philox(counter, key):
+    """Philox4x64-10 of csrc/mcd_rng.h: counter (4 words), key (2 words) -> 4 words."""
+    c = np.ascontiguousarray(counter, dtype=np.uint64)
+    k = np.ascontiguousarray(key, dtype=np.uint64)
+    out = np.empty(4, dtype=np.uint64)
+    lib().emul_philox.argtypes = [ctypes.c_void_p] * 3
+    lib().emul_philox.restype = None
+    lib().emul_philox(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def det_log(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().emul_det_log.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    lib().emul_det_log.restype = None
+    lib().emul_det_log(x.size, x.ctypes.data, out.ctypes.data)
+    return out
+
+
+def chain_numbers(seed, step0, n_steps, n_bins, n_walkers, n_dim):
+    """order [n][B][W], zz / thr / pick [n][2][B][W/2] of steps step0 .. step0 + n - 1 (host build of csrc/mcd_rng.h)."""
+    B, W, half = max(int(n_bins), 1), int(n_walkers), int(n_walkers) // 2
+    order = np.empty((n_steps, B, W), dtype=np.int32)
+    zz = np.empty((n_steps, 2, B, half))
+    thr = np.empty((n_steps, 2, B, half))
+    pick = np.empty((n_steps, 2, B, half), dtype=np.int32)
+    L = lib()
+    L.emul_chain_numbers.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + \
+        [ctypes.c_void_p] * 4
+    L.emul_chain_numbers.restype = None
+    L.emul_chain_numbers(seed, step0, n_steps, B, W, n_dim, order.ctypes.data, zz.ctypes.data, thr.ctypes.data, pick.ctypes.data)
+    return order, zz, thr, pick
+
+
+def chain_keys(seed, step, b, n_walkers):
+    out = np.empty(int(n_walkers))
+    L = lib()
+    L.emul_chain_keys.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    L.emul_chain_keys.restype = None
+    L.emul_chain_keys(seed, step, b, n_walkers, out.ctypes.data)
+    return out

@@ -440,3 +440,97 @@ def test_hundreds_of_ensembles(native):
     assert info["device_blocks"] == 3 and info["host_blocks"] == 3 and info["discarded_blocks"] == 0, info
     assert all(np.array_equal(a, b) for a, b in zip(*res)) and np.all(np.isfinite(res[0][1]))
     bf.close()
+
+
+def run_seeded(cat, plan, pos, lnp, seed, step0, n_steps, device):
+    cat.set_option("device_chain", int(device))
+    pos, lnp = pos.copy(), lnp.copy()
+    lead = pos.shape[:-1]
+    chain, lnpc, acc = np.empty((n_steps,) + pos.shape), np.empty((n_steps,) + lead), np.zeros(lead, dtype=np.int64)
+    cat.stretch_move_seeded(plan, pos, lnp, seed, step0, n_steps, chain, lnpc, acc)
+    return pos, lnp, chain, lnpc, acc
+
+
+@pytest.mark.parametrize("model,free,w", [(0, False, 48), (0, False, 512), (2, True, 64), (5, False, 130)])
+def test_seeded_blocks_generate_their_numbers_on_the_device(native, ctx, model, free, w):
+    """`mcd_stretch_move_seeded`: the step kernel generates the block's random numbers (csrc/mcd_rng.h) -- against (a) the
+    host-driven block of the same call (numbers generated on the host by the same functions), (b) `mcd_stretch_move` fed
+    with `mcd_chain_numbers` of the same (seed, steps), resident and host-driven, (c) the same steps cut into two calls:
+    every bit equal.  512 walkers: two walkers per thread in the ranking of the ordering keys; 130: a ragged last wave."""
+    rng = np.random.default_rng(9700 + 10 * model + free + w)
+    cat, sv = _catalogue(native, ctx, rng, 30011, model, free)
+    pos = _walkers(rng, w, model, sv, free)
+    lo, hi = np.full(cat.k, -np.inf), np.full(cat.k, np.inf)
+    lo[1] = 0.0
+    lo[0], hi[0] = pos[:, 0].min() - 0.1 * sv, pos[:, 0].max() + 0.1 * sv
+    if model in (2, 4, 5):
+        lo[-1], hi[-1] = 0.0, 1.0
+    if model >= 3:
+        lo[2] = lo[5] = 1.0
+    plan = identity_plan(cat.k, lo, hi)
+    lnp = cat.loglike(pos)
+    seed, step0, n = 0xC0FFEE1234567 + model, 1000, 17
+    before = cat.stretch_info()
+    dev = run_seeded(cat, plan, pos, lnp, seed, step0, n, device=1)
+    mid = cat.stretch_info()
+    assert mid["device_blocks"] == before["device_blocks"] + 1 and mid["discarded_blocks"] == before["discarded_blocks"], mid
+    host = run_seeded(cat, plan, pos, lnp, seed, step0, n, device=0)
+    after = cat.stretch_info()
+    assert after["host_blocks"] == mid["host_blocks"] + 1
+    assert same(dev, host)
+    numbers = native.chain_numbers(seed, step0, n, 1, w, cat.k, squeeze=True)
+    numbers = tuple(np.ascontiguousarray(a) for a in numbers)
+    assert same(dev, run_block(cat, plan, pos, lnp, numbers, device=True))
+    assert same(dev, run_block(cat, plan, pos, lnp, numbers, device=False))
+    first = run_seeded(cat, plan, pos, lnp, seed, step0, 6, device=1)
+    second = run_seeded(cat, plan, first[0], first[1], seed, step0 + 6, n - 6, device=1)
+    assert np.array_equal(np.concatenate([first[2], second[2]]), dev[2]) and np.array_equal(second[1], dev[1])
+    assert np.array_equal(first[4] + second[4], dev[4])
+    assert 0 < dev[4].sum() < n * w and np.all(np.isfinite(dev[3]))
+    other = run_seeded(cat, plan, pos, lnp, seed + 1, step0, n, device=1)
+    assert not np.array_equal(other[2], dev[2])
+    # ensembles the in-LDS step kernel does not take (option 2: the general step kernel) are run host-driven: same chain
+    before = cat.stretch_info()
+    assert same(dev, run_seeded(cat, plan, pos, lnp, seed, step0, n, device=2))
+    assert cat.stretch_info()["host_blocks"] == before["host_blocks"] + 1
+    cat.close()
+
+
+@pytest.mark.parametrize("parts", [False, True])
+def test_seeded_binned_blocks_and_the_sampler_modes(native, parts, monkeypatch):
+    """B ensembles with device-generated numbers: resident == host-driven == the NumPy loop of BinnedSampler fed by
+    `chain_numbers` (rng="device" without a block function), also with every block cut into parts."""
+    from mcmc_dynamics_amd import DataReader
+    from mcmc_dynamics_amd.analysis import BinnedConstantFit
+    from mcmc_dynamics_amd.analysis.binned import BinnedSampler
+    if parts:
+        monkeypatch.setenv("MCD_CHAIN_PART_BYTES", "1")
+    g = load_golden("radial_bins")
+    reader = DataReader({k: g[k] for k in ("ra", "dec", "v", "verr")})
+    reader.make_radial_bins(float(g["ra_center"]), float(g["dec_center"]), nstars=200, dlogr=0.05)
+    bf = BinnedConstantFit(reader)
+    bf.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+    bf.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+    B, W, P = bf.n_bins, 40, 4
+    rng = np.random.default_rng(9800)
+    pos = np.array([3.0, 9.0, 1.0, -1.0]) * (1.0 + 0.2 * rng.normal(size=(B, W, P)))
+    pos[..., 1] = np.abs(pos[..., 1]) + 0.5
+    pos = np.ascontiguousarray(pos)
+    res = []
+    for mode, seeded_fn, block_steps in ((1, bf._stretch_block_seeded, 256), (0, bf._stretch_block_seeded, 9), (1, None, 11)):
+        s = BinnedSampler(B, W, P, bf.lnprob_batch, seed=77, rng="device", seeded_block_fn=seeded_fn)
+        s.device_block_steps = block_steps
+        bf._ensure_catalog().set_option("device_chain", mode)
+        s.run_mcmc(pos, 23)
+        res.append((s.chain.copy(), s.lnprobability.copy(), s.acceptance_fraction.copy()))
+        s.close()
+    info = bf._catalog.stretch_info()
+    assert info["device_blocks"] == 1 and info["host_blocks"] == 3 and info["discarded_blocks"] == 0, info
+    assert same(res[0], res[1]) and same(res[0], res[2])
+    assert np.all(np.isfinite(res[0][1])) and np.all(res[0][2] > 0)
+    # the class's own entry point uses the device generator by default
+    np.random.seed(4)
+    s = bf(n_walkers=W, n_steps=6, pos=pos)
+    assert s.rng == "device" and s.chain.shape == (B, W, 6, P)
+    s.close()
+    bf.close()

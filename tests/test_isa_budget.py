@@ -18,7 +18,7 @@ BUDGET = {                                   # VALU instructions per star-walker
     "BGGAUSS fixed centre": 53.6,
     "BGGAUSS fixed, narrow": 45.1,
     "PROFILE fixed centre": 25.1,
-    "PROFILE fixed, narrow": 21.0,       # round 3: no reciprocal per term, one-step Newton root (ProfileNarrowAcc)
+    "PROFILE fixed, narrow": 22.6,       # round 3: no reciprocal per term, one-step Newton root (ProfileNarrowAcc)
     # the instantiations that prefetch the next iteration's records (mcd_math.h: RecordPrefetch): + 2 instructions per
     # iteration (lane index and predicate are hoisted, the touch and its exec mask are not)
     "CONST fixed centre, prefetch": 8.7,

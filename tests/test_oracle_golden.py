@@ -311,7 +311,7 @@ def test_builtin_stretch_move_samples_like_emcees_default_move():
         return out
 
     n_steps, burn = 700, 200
-    acc, med, std = {"builtin": [], "emcee": []}, {"builtin": [], "emcee": []}, []
+    acc, med, std = {"builtin": [], "emcee": [], "device_rng": []}, {"builtin": [], "emcee": [], "device_rng": []}, []
     for seed in (11, 12, 13):
         rng = np.random.default_rng(seed)
         pos = np.column_stack([rng.normal(0, 1, 32), rng.lognormal(2.2, 0.2, 32), rng.normal(0, 1, 32), rng.normal(0, 1, 32)])
@@ -321,6 +321,12 @@ def test_builtin_stretch_move_samples_like_emcees_default_move():
         acc["builtin"].append(s.acceptance_fraction.mean())
         med["builtin"].append(np.median(flat, axis=0))
         std.append(flat.std(axis=0))
+        # ... and the same move with the counter-based random numbers of csrc/mcd_rng.h (rng="device": what the step kernel
+        # generates for seeded blocks; here through the library's host entry point mcd_chain_numbers)
+        s = EnsembleSampler(32, 4, lnprob, vectorize=True, seed=seed, rng="device")
+        s.run_mcmc(pos, n_steps)
+        acc["device_rng"].append(s.acceptance_fraction.mean())
+        med["device_rng"].append(np.median(s.get_chain(discard=burn, flat=True), axis=0))
         chain, frac = _emcee_stretch_reference(lnprob, pos, n_steps, seed + 100)
         acc["emcee"].append(frac.mean())
         med["emcee"].append(np.median(chain[burn:].reshape(-1, 4), axis=0))
@@ -328,4 +334,7 @@ def test_builtin_stretch_move_samples_like_emcees_default_move():
     assert abs(np.mean(acc["builtin"]) - np.mean(acc["emcee"])) < 0.03, acc
     assert 0.3 < np.mean(acc["builtin"]) < 0.8
     diff = np.abs(np.mean(med["builtin"], axis=0) - np.mean(med["emcee"], axis=0)) / sigma
+    assert np.all(diff < 0.2), (diff, med, sigma)
+    assert abs(np.mean(acc["device_rng"]) - np.mean(acc["emcee"])) < 0.03, acc
+    diff = np.abs(np.mean(med["device_rng"], axis=0) - np.mean(med["emcee"], axis=0)) / sigma
     assert np.all(diff < 0.2), (diff, med, sigma)

@@ -176,3 +176,43 @@ def test_binned_block_equals_the_python_loop_of_the_binned_sampler():
     ref.run_mcmc(ref.chain[:, :, -1, :], 7, log_prob0=ref.lnprobability[:, :, -1])
     nat.run_mcmc(pos, 7, log_prob0=lnp)
     assert np.array_equal(nat.chain, ref.chain) and nat.iteration == 47
+
+
+def test_device_rng_mode_python_loop_is_block_partition_invariant():
+    """rng="device" (csrc/mcd_rng.h): the chain is a function of (seed, step, bin, walker) -- the Python loops of both
+    samplers, fed by `_native.chain_numbers`, give the same chain however a run is cut into blocks or run_mcmc calls, and
+    the chain samples the target (a standard normal: mean and variance within sampling error)."""
+    from mcmc_dynamics_amd.analysis.binned import BinnedSampler
+    from mcmc_dynamics_amd.sampler import EnsembleSampler
+
+    def lnprob(values):
+        return -0.5 * np.sum(np.asarray(values) ** 2, axis=-1)
+
+    B, W, P = 3, 12, 2
+    rng = np.random.default_rng(0)
+    start = rng.normal(size=(B, W, P))
+    a = BinnedSampler(B, W, P, lnprob, seed=123, rng="device")
+    a.run_mcmc(start, 40)
+    b = BinnedSampler(B, W, P, lnprob, seed=123, rng="device")
+    b.device_block_steps = 7
+    pos, lnp, _ = b.run_mcmc(start, 13)
+    b.run_mcmc(pos, 27, log_prob0=lnp)
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(a.lnprobability, b.lnprobability)
+    c = BinnedSampler(B, W, P, lnprob, seed=124, rng="device")
+    c.run_mcmc(start, 40)
+    assert not np.array_equal(a.chain, c.chain)
+    for s in (a, b, c):
+        s.close()
+
+    e = EnsembleSampler(W, P, lnprob, vectorize=True, seed=5, rng="device")
+    e.run_mcmc(start[0], 6000)
+    f = EnsembleSampler(W, P, lnprob, vectorize=True, seed=5, rng="device")
+    f.block_steps = 37
+    pos, lnp, _ = f.run_mcmc(start[0], 250)
+    f.run_mcmc(pos, 5750, log_prob0=lnp)
+    assert np.array_equal(e.chain, f.chain)
+    flat = e.chain[:, 200:].reshape(-1, P)
+    assert np.all(np.abs(flat.mean(axis=0)) < 0.1) and np.all(np.abs(flat.var(axis=0) - 1.0) < 0.1)
+    assert 0.4 < e.acceptance_fraction.mean() < 0.95
+    with pytest.raises(ValueError):
+        EnsembleSampler(W, P, lnprob, rng="device", a=3.0)

@@ -23,6 +23,15 @@ for bs in (64, 128, 256):
     state = s.run_mcmc(pos, bs + 6)
     t0 = time.perf_counter(); s.run_mcmc(state[0], 512, log_prob0=state[1]); dt = time.perf_counter() - t0
     print("B {0} W {1} block_steps {5}: library blocks {2:.1f} us per step ({3:.0f} steps/s) {4}".format(B, W, dt / 512 * 1e6, 512 / dt, fit._catalog.stretch_info(), bs), flush=True)
+for bs in (64, 256):
+    s = BinnedSampler(B, W, 4, fit.lnprob_batch, seed=1, rng="device", seeded_block_fn=fit._stretch_block_seeded)
+    s.device_block_steps = bs
+    state = s.run_mcmc(pos, bs)
+    t0 = time.perf_counter(); s.run_mcmc(state[0], 512, log_prob0=state[1]); dt = time.perf_counter() - t0
+    print("B {0} W {1} block_steps {5}: SEEDED library blocks {2:.1f} us per step ({3:.0f} steps/s) {4}".format(B, W, dt / 512 * 1e6, 512 / dt, fit._catalog.stretch_info(), bs), flush=True)
+    s.close()
+if len(sys.argv) > 3 and sys.argv[3] == "seeded-only":
+    sys.exit(0)
 half = W // 2
 tab = np.ascontiguousarray(np.broadcast_to(pos1[:half], (B, half, 4)))
 g = fit._catalog
