@@ -616,6 +616,14 @@ def main():
             dt_host = timed_chain()
             fit_cat.set_option("device_chain", 1)
             mcmc["host_driven_steps_per_s"] = n_mcmc / dt_host
+            # the same blocks with the random numbers generated on the device (Runner.RNG = "device", csrc/mcd_rng.h)
+            from mcmc_dynamics_amd.sampler import EnsembleSampler
+            dev_sampler = EnsembleSampler(n_walkers, fit.n_fitted_parameters, fit.lnprob_batch, vectorize=True, seed=3,
+                                          rng="device", seeded_block_fn=fit._stretch_block_seeded)
+            dev_state = dev_sampler.run_mcmc(start, 300)
+            t2 = time.perf_counter()
+            dev_sampler.run_mcmc(dev_state[0], n_mcmc, log_prob0=dev_state[1])
+            mcmc["device_rng_steps_per_s"] = n_mcmc / (time.perf_counter() - t2)
         fit.close()
 
     if world == 1 and n_bins > 1 and not args.no_mcmc and model == "const" and args.precision == "f64":
@@ -632,12 +640,13 @@ def main():
         fit.parameters["ra_center"].set(value=synthetic.CENTER_RA_DEG, fixed=True)
         fit.parameters["dec_center"].set(value=synthetic.CENTER_DEC_DEG, fixed=True)
         rates = {}
-        # "library": the default (BinnedConstantFit.RNG = "device": numbers generated in the step kernel, csrc/mcd_rng.h);
+        # "library": the default (BinnedConstantFit.RNG = "device": numbers generated on the device, csrc/mcd_rng.h);
         # "host_numbers": the same blocks with NumPy's generator on the host (rng="host"); "numpy_loop": no library blocks
         for label, block_fn, n_mcmc, rng_mode in (("library", fit._stretch_block, 256, "device"),
                                                   ("host_numbers", fit._stretch_block, 256, "host"), ("numpy_loop", None, 8, "host")):
             sampler = BinnedSampler(fit.n_bins, n_walkers, fit.n_fitted_parameters, fit.lnprob_batch, seed=5, block_fn=block_fn,
                                     rng=rng_mode, seeded_block_fn=fit._stretch_block_seeded if block_fn is not None else None)
+            sampler.reserve(520)                             # (one allocation for the warm-up and the timed run)
             state = sampler.run_mcmc(pos, 4 if block_fn is None else 256)     # (untimed: also sizes the block arena)
             t2 = time.perf_counter()
             sampler.run_mcmc(state[0], n_mcmc, log_prob0=state[1])
@@ -648,7 +657,7 @@ def main():
         mcmc = {"steps_per_s": rates["library"], "terms_per_s": float(len(cat["v"])) * n_walkers * rates["library"],
                 "driver": "mcmc_dynamics_amd.analysis.binned.BinnedSampler", "posterior": "BinnedConstantFit.lnprob_batch",
                 "ensembles": fit.n_bins, "calls_per_step": 2, "walkers_per_call": n_walkers // 2, "steps": 256,
-                "acceptance_fraction": acc, "random_numbers": "generated in the step kernel (Philox4x64-10, csrc/mcd_rng.h)",
+                "acceptance_fraction": acc, "random_numbers": "generated on the device (Philox4x64-10, csrc/mcd_rng.h: chain_numbers_kernel)",
                 "host_numbers_steps_per_s": rates["host_numbers"], "numpy_loop_steps_per_s": rates["numpy_loop"],
                 "stretch_blocks": fit._catalog.stretch_info()}
         fit.close()

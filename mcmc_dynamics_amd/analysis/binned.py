@@ -38,7 +38,7 @@ class BinnedSampler(object):
 
         ``"device"``: the counter-based generator of csrc/mcd_rng.h (Philox4x64-10): every number is a function of (seed,
         step, half step, bin, walker) alone.  ``seeded_block_fn`` (``Runner._stretch_block_seeded``) runs whole blocks with
-        the numbers generated inside the step kernel; without it (expression priors) the NumPy loop below takes the SAME
+        the numbers generated on the device (csrc/mcd_stretch.hip: chain_numbers_kernel); without it (expression priors) the NumPy loop below takes the SAME
         numbers from ``_native.chain_numbers`` -- one chain whichever way it is run, and however it is cut into blocks."""
         if nwalkers % 2 or nwalkers < 2 * ndim:
             raise ValueError("need an even number of walkers, at least twice the dimension")
@@ -95,6 +95,15 @@ class BinnedSampler(object):
     def acceptance_fraction(self):
         return self._accepted / max(1, self.iteration)
 
+    def reserve(self, total_steps):
+        """Chain storage for ``total_steps`` steps in all (a run continued by further ``run_mcmc`` calls otherwise grows its
+        storage geometrically and copies the rows it holds: 1.1 MB per step at 55 bins x 512 walkers)."""
+        B, W, P = self.n_bins, self.nwalkers, self.ndim
+        if int(total_steps) > self._chain.shape[0]:
+            chain, lnprob = np.empty((int(total_steps), B, W, P)), np.empty((int(total_steps), B, W))
+            chain[:self.iteration], lnprob[:self.iteration] = self._chain[:self.iteration], self._lnprob[:self.iteration]
+            self._chain, self._lnprob = chain, lnprob
+
     def run_mcmc(self, pos, nsteps, log_prob0=None):
         pos = np.ascontiguousarray(pos, dtype=np.float64).copy()
         B, W, P = self.n_bins, self.nwalkers, self.ndim
@@ -106,10 +115,7 @@ class BinnedSampler(object):
         nsteps = int(nsteps)
         need = self.iteration + nsteps
         if need > self._chain.shape[0]:
-            cap = max(need, 2 * self._chain.shape[0])
-            chain, lnprob = np.empty((cap, B, W, P)), np.empty((cap, B, W))
-            chain[:self.iteration], lnprob[:self.iteration] = self._chain[:self.iteration], self._lnprob[:self.iteration]
-            self._chain, self._lnprob = chain, lnprob
+            self.reserve(max(need, 2 * self._chain.shape[0]))
         half = W // 2
         rows = np.arange(B)[:, None]
         am1, inv_a, dm1 = self.a - 1.0, 1.0 / self.a, P - 1.0
@@ -160,7 +166,7 @@ class BinnedSampler(object):
             if self.seeded_block_fn is None:
                 from .. import _native as native
 
-                def draw(n):                                 # noqa: F811 -- the same numbers the step kernel generates
+                def draw(n):                                 # noqa: F811 -- the same numbers the device generates
                     return native.chain_numbers(self.seed64, self.iteration, n, B, W, P)
         pending = None
         while done < nsteps:

@@ -421,7 +421,7 @@ class Runner(object):
                                seeded_block_fn=self._stretch_block_seeded if resident else None)
 
     # the built-in move's random numbers: "host" -- NumPy's Mersenne twister, drawn on the host as emcee does; "device" --
-    # the counter-based generator of csrc/mcd_rng.h inside the step kernel (a function of (seed, step, walker): no numbers
+    # the counter-based generator of csrc/mcd_rng.h in a kernel of its own (a function of (seed, step, walker): no numbers
     # cross PCIe, the chain does not depend on how it is cut into blocks)
     RNG = "host"
     NATIVE_STRETCH = True          # sub-classes whose posterior is not ONE un-binned catalogue switch this off

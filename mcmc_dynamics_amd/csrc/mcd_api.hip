@@ -823,8 +823,13 @@ int fetch(mcd_catalog* cat, double* out) {
 void big_copy(void* dst, const void* src, size_t bytes) {
     constexpr size_t kSerial = (size_t)4 << 20;
     if (bytes < kSerial) { std::memcpy(dst, src, bytes); return; }
-    constexpr int kThreads = 4;
-    std::thread workers[kThreads - 1];
+    constexpr int kMaxThreads = 16;
+    static const int kThreads = [] {
+        const char* e = std::getenv("MCD_COPY_THREADS");                  // tuning aid
+        const int n = e ? std::atoi(e) : 4;
+        return n < 1 ? 1 : (n > kMaxThreads ? kMaxThreads : n);
+    }();
+    std::thread workers[kMaxThreads - 1];
     const size_t part = (bytes / kThreads + 63) / 64 * 64;
     int started = 0;
     for (int t = 1; t < kThreads; ++t) {
@@ -842,8 +847,8 @@ void big_copy(void* dst, const void* src, size_t bytes) {
     (void)started;
 }
 
-// `seed` != nullptr: a seeded block (mcd_stretch_move_seeded) -- order / zz / thr / pick are null, the step kernel generates
-// the numbers of absolute steps step0 .. step0 + n_steps - 1 itself (mcd_rng.h)
+// `seed` != nullptr: a seeded block (mcd_stretch_move_seeded) -- order / zz / thr / pick are null, a kernel generates the
+// numbers of absolute steps step0 .. step0 + n_steps - 1 on the device (mcd_rng.h, mcd_stretch.hip: chain_numbers_kernel)
 int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, double* pos, double* lnp,
                          const int32_t* order, const double* zz, const double* thr, const int32_t* pick, double* chain,
                          double* lnprob_chain, int64_t* accepted, bool* done, const uint64_t* seed = nullptr,
@@ -863,7 +868,6 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         probe.n_bins = B; probe.n_walkers = W; probe.n_dim = P; probe.k = K;
         probe.force_general = cat->device_chain == 2;
         if (!mcd::stretch_step_handles(probe)) return MCD_OK;
-        if (seed && !mcd::stretch_step_fuses(probe)) return MCD_OK;          // (only the in-LDS step kernel generates numbers)
     }
     Shard& sh = cat->shards[0];
     const DeviceSlot& slot = ctx->slots[sh.slot];
@@ -890,11 +894,13 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     const size_t o_src = take((size_t)K * 4), o_const = take((size_t)K * 8), o_fac = take((size_t)K * 8);
     const size_t o_lo = take((size_t)P * 8), o_hi = take((size_t)P * 8);
     const bool seeded = seed != nullptr;
-    const size_t n_in = seeded ? 0 : (size_t)n_steps;                    // seeded blocks upload no numbers
+    // seeded blocks: a kernel writes the numbers where the upload would have put them (ensembles too large for it: the host
+    // build of the same functions fills the pinned copy, uploaded as usual)
+    const bool gen_device = seeded && mcd::chain_numbers_on_device(W);
+    const size_t n_in = (size_t)n_steps;
     const size_t o_order = take(n_in * BW * 4), o_zz = take(n_in * BW * 8);
     const size_t o_thr = take(n_in * BW * 8), o_pick = take(n_in * BW * 4);
     const size_t input_end = off;
-    const size_t o_order_scratch = take(seeded ? BW * 4 : 0), o_thr_scratch = take(seeded ? BW * 8 : 0);
     const size_t o_prop = take(Bh * P * 8), o_ok = take(Bh), o_nok = take((size_t)2 * B * 4), o_ranges = take((size_t)2 * B * 10 * 8);
     const size_t o_chain = take(chain ? (size_t)n_steps * BW * P * 8 : 0);
     const size_t o_lnpc = take(lnprob_chain ? (size_t)n_steps * BW * 8 : 0);
@@ -939,7 +945,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     // Blocks that move tens of MB (binned catalogues: the random numbers of 64 steps of 55 x 512 walkers are 40 MB, their
     // chain rows 70 MB -- a third of the block's device time in copies) are cut into parts: the host copies and the PCIe
     // transfers of one part overlap the device work of another (copies on the second stream, joined by events).
-    const size_t moved = (size_t)n_steps * BW * ((seeded ? 0 : 24) + (chain ? (size_t)P * 8 : 0) + (lnprob_chain ? 8 : 0));
+    const size_t moved = (size_t)n_steps * BW * ((gen_device ? 0 : 24) + (chain ? (size_t)P * 8 : 0) + (lnprob_chain ? 8 : 0));
     size_t part_threshold = (size_t)16 << 20;
     if (const char* e = std::getenv("MCD_CHAIN_PART_BYTES")) part_threshold = (size_t)std::strtoull(e, nullptr, 10);   // testing aid
     // (what stays exposed is the first part's numbers going in and the last part's rows coming out: 1 / n_parts of the copies.
@@ -949,8 +955,16 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     const int64_t n_parts = moved >= part_threshold ? std::min<int64_t>(max_parts, n_steps) : 1;
     auto part_begin = [&](int64_t k) { return n_steps * k / n_parts; };
     auto copy_in = [&](int64_t i0, int64_t i1) {              // the random numbers of steps i0 .. i1: user -> pinned
-        if (seeded) return;
+        if (gen_device) return;
         const size_t at = (size_t)i0 * BW, n = (size_t)(i1 - i0) * BW;
+        if (seeded) {
+            std::vector<uint64_t> sorter;
+            for (int64_t i = i0; i < i1; ++i)
+                mcd::chain_numbers_of_step(*seed, step0 + i, B, W, P, (int32_t*)(a.h + o_order) + (size_t)i * BW,
+                                           (double*)(a.h + o_zz) + (size_t)i * BW, (double*)(a.h + o_thr) + (size_t)i * BW,
+                                           (int32_t*)(a.h + o_pick) + (size_t)i * BW, sorter);
+            return;
+        }
         big_copy(a.h + o_order + at * 4, order + at, n * 4);
         big_copy(a.h + o_zz + at * 8, zz + at, n * 8);
         big_copy(a.h + o_thr + at * 8, thr + at, n * 8);
@@ -983,11 +997,6 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     sd.pos = (double*)(a.d + o_pos); sd.lnp = (double*)(a.d + o_lnp); sd.accepted = (long long*)(a.d + o_acc);
     sd.order = (const int32_t*)(a.d + o_order); sd.zz = (const double*)(a.d + o_zz); sd.thr = (const double*)(a.d + o_thr);
     sd.pick = (const int32_t*)(a.d + o_pick);
-    if (seeded) {
-        sd.order = nullptr; sd.zz = nullptr; sd.thr = nullptr; sd.pick = nullptr;
-        sd.seeded = 1; sd.seed = *seed; sd.step0 = step0;
-        sd.order_scratch = (int32_t*)(a.d + o_order_scratch); sd.thr_scratch = (double*)(a.d + o_thr_scratch);
-    }
     sd.chain = chain ? (double*)(a.d + o_chain) : nullptr;
     sd.lnprob_chain = lnprob_chain ? (double*)(a.d + o_lnpc) : nullptr;
     sd.proposal = (double*)(a.d + o_prop); sd.ok = (uint8_t*)(a.d + o_ok); sd.meta = (int32_t*)(a.d + o_meta);
@@ -1078,8 +1087,13 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         }
     } mid_block{ctx, coll, false};
     bool rows_delivered = false;                               // chain rows already in the caller's arrays (parts)
+    auto generate = [&](hipStream_t s, int64_t i0, int64_t i1) {   // seeded: the numbers of steps i0 .. i1, on the device
+        return mcd::launch_chain_numbers(s, *seed, step0, i0, i1, B, W, P, (int32_t*)(a.d + o_order), (double*)(a.d + o_zz),
+                                         (double*)(a.d + o_thr), (int32_t*)(a.d + o_pick));
+    };
     if (n_parts == 1) {
-        MCD_HIP(hipMemcpyAsync(a.d, a.h, input_end, hipMemcpyHostToDevice, slot.stream));
+        MCD_HIP(hipMemcpyAsync(a.d, a.h, gen_device ? o_order : input_end, hipMemcpyHostToDevice, slot.stream));
+        if (gen_device) MCD_HIP(generate(slot.stream, 0, n_steps));
         rc = enqueue_steps(0, n_steps, nullptr);
         if (rc != MCD_OK) return rc;
         rc = finish();
@@ -1119,7 +1133,11 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         for (int64_t k = 0; k < n_parts; ++k) {
             const int64_t i0 = part_begin(k), i1 = part_begin(k + 1);
             const size_t at = (size_t)i0 * BW, n = (size_t)(i1 - i0) * BW;
-            if (!seeded) {
+            if (gen_device) {
+                MCD_HIP(generate(slot.comm_stream, i0, i1));
+                MCD_HIP(hipEventRecord(ev_in[k], slot.comm_stream));
+                MCD_HIP(hipStreamWaitEvent(slot.stream, ev_in[k], 0));
+            } else {
                 copy_in(i0, i1);
                 MCD_HIP(hipMemcpyAsync(a.d + o_order + at * 4, a.h + o_order + at * 4, n * 4, hipMemcpyHostToDevice, slot.comm_stream));
                 MCD_HIP(hipMemcpyAsync(a.d + o_zz + at * 8, a.h + o_zz + at * 8, n * 8, hipMemcpyHostToDevice, slot.comm_stream));
@@ -1677,7 +1695,7 @@ int run_stretch(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, do
     // a time, so that a block of any length needs the numbers of one step only
     std::vector<int32_t> g_order, g_pick;
     std::vector<double> g_zz, g_thr, g_keys;
-    std::vector<std::pair<double, int32_t>> sorter;
+    std::vector<uint64_t> sorter;
     int eval_rc = MCD_OK;
     auto eval = [&](const double* table, int64_t n, double* out) {
         eval_rc = mcd_loglike_batch(cat, n, d->k, table, out);
@@ -1723,7 +1741,7 @@ int mcd_chain_numbers(uint64_t seed, int64_t step0, int64_t n_steps, int64_t n_b
     if (!order || !zz || !thr || !pick || n_steps < 0 || step0 < 0 || n_walkers <= 0 || (n_walkers & 1) || n_dim <= 0)
         return fail(MCD_ERR_INVALID, "mcd_chain_numbers: bad arguments");
     const int64_t B = n_bins > 1 ? n_bins : 1, W = n_walkers, half = W / 2;
-    std::vector<std::pair<double, int32_t>> sorter;
+    std::vector<uint64_t> sorter;
     for (int64_t i = 0; i < n_steps; ++i)
         mcd::chain_numbers_of_step(seed, step0 + i, B, W, n_dim, order + (size_t)i * B * W, zz + (size_t)i * 2 * B * half,
                                    thr + (size_t)i * 2 * B * half, pick + (size_t)i * 2 * B * half, sorter);

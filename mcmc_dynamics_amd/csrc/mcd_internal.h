@@ -83,14 +83,6 @@ struct StretchDevice {
     long long launch_index = 0;
 #endif
     int32_t force_general = 0;             // testing aid (option "device_chain" = 2): the general step kernel for any size
-    // seeded blocks (mcd_stretch_move_seeded): the block's random numbers are generated where they are used (mcd_rng.h) --
-    // order / zz / thr / pick above are null; the step kernel keeps the current step's split and the pending acceptance
-    // thresholds in the two scratch arrays
-    int32_t seeded = 0;
-    uint64_t seed = 0;
-    int64_t step0 = 0;                     // absolute index of the block's first step (the counter of the generator)
-    int32_t* order_scratch = nullptr;      // [B][W]
-    double* thr_scratch = nullptr;         // [2][B][W/2] by half-step parity
     // fused reduction (launches whose partial sums are few, kFusedReduceSlots): the step kernel adds up the main kernel's
     // partial sums itself instead of reading the sums a reduction kernel left in `ll` -- one kernel less per half step
     int32_t fused = 0;
@@ -125,6 +117,11 @@ struct StretchDevice {
 hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t acc_step, int acc_h, int64_t prop_step,
                                int prop_h, const double* ll, double rerun_tag);
 hipError_t launch_stretch_status(hipStream_t s, const int32_t* meta, double* out);
+// seeded blocks: the numbers of steps [i0, i1) of a block generated on the device, in the layout of the host's upload
+// (mcd_rng.h); ensembles whose keys do not fit in LDS get their numbers from the host build of the same functions
+bool chain_numbers_on_device(int64_t n_walkers);
+hipError_t launch_chain_numbers(hipStream_t s, uint64_t seed, int64_t step0, int64_t i0, int64_t i1, int64_t n_bins,
+                                int64_t n_walkers, int n_dim, int32_t* order, double* zz, double* thr, int32_t* pick);
 // several ensembles need the step kernel that keeps an ensemble in LDS (<= 512 walkers, <= 12 columns, <= 32 KiB of positions)
 bool stretch_step_handles(const StretchDevice& d);
 // ... and only that kernel can add up the main kernel's partial sums itself (StretchDevice::fused)

@@ -1,7 +1,7 @@
-// mcd_rng.h -- counter-based random numbers of the stretch move, the same code on the device (mcd_stretch.hip generates a
-// block's numbers where they are used: nothing crosses PCIe) and on the host (the host-driven block of mcd_api.hip, the CPU
-// test harness tests/emul), so that a chain is a function of (seed, step, half step, ensemble, walker) alone and any step of
-// it can be replayed anywhere.
+// mcd_rng.h -- counter-based random numbers of the stretch move, the same code on the device (mcd_stretch.hip:
+// chain_numbers_kernel fills a seeded block's numbers in device memory: nothing crosses PCIe) and on the host (the host-driven
+// block of mcd_api.hip, mcd_chain_numbers, the CPU test harness tests/emul), so that a chain is a function of (seed, step,
+// half step, ensemble, walker) alone and any step of it can be replayed anywhere.
 //
 //   * generator: Philox4x64-10 (Salmon et al. 2011), the algorithm of NumPy's `numpy.random.Philox` bit generator --
 //     tests/test_chain_rng_cpu.py checks this implementation against `numpy.random.Philox(key=..., counter=...).random_raw`
@@ -90,22 +90,23 @@ MCD_HD double det_log(double x) {
 }
 
 // ---- the numbers of a chain --------------------------------------------------------------------------------------
-// counter = (step, kind | half step, ensemble, walker-or-slot); key = (seed, a constant that names this use of the generator).
-//   kind 0: the key that orders walker w of ensemble b in step i (the split of the ensemble = argsort of the keys, ties by
-//           walker index): output 0
-//   kind 1 + h: slot j of half step h: output 0 -> stretch factor z, 1 -> acceptance uniform, 2 -> partner index
+// ONE generator call per walker and step: counter = (step, half step h, ensemble b, slot j), key = (seed, a constant that
+// names this use of the generator).  Its four words:
+//   0 -> stretch factor z of slot j in half step h          1 -> that slot's acceptance uniform
+//   2 -> that slot's partner index                           3 -> ordering key of walker w = h W/2 + j in this step
+// The split of the ensemble in a step = the walkers sorted by (ordering key, walker index), where the ordering key is the
+// word's upper 44 bits: the device ranks by counting with ONE unsigned comparison per pair on (key << 20 | walker), which is
+// why ensembles are limited to 2^20 walkers here.
 constexpr uint64_t kChainKey1 = 0x6d63645f636861ull;          // "mcd_cha"
+constexpr int kOrderKeyShift = 20;
+constexpr int64_t kSeededMaxWalkers = (int64_t)1 << kOrderKeyShift;
 
-MCD_HD double chain_order_key(uint64_t seed, int64_t step, int64_t b, int64_t w) {
-    return uniform53(philox4x64_10((uint64_t)step, 0, (uint64_t)b, (uint64_t)w, seed, kChainKey1).v[0]);
-}
-
-struct ChainDraw { double z, thr; int32_t pick; };
+struct ChainDraw { double z, thr; int32_t pick; uint64_t order_key; };
 
 // a = 2 (emcee's default): z = ((a - 1) u + 1)^2 / a, thr = log(u') - (P - 1) log z, partner = floor(u'' half) -- the
-// operations of sampler.py's draw(), with det_log for the logarithms
+// operations of sampler.py's draw(), with det_log for the logarithms.  order_key: (upper 44 bits) << 20 | walker.
 MCD_HD ChainDraw chain_draw(uint64_t seed, int64_t step, int h, int64_t b, int64_t j, int64_t half, int n_dim) {
-    const Philox4x64 r = philox4x64_10((uint64_t)step, (uint64_t)(1 + h), (uint64_t)b, (uint64_t)j, seed, kChainKey1);
+    const Philox4x64 r = philox4x64_10((uint64_t)step, (uint64_t)h, (uint64_t)b, (uint64_t)j, seed, kChainKey1);
     ChainDraw d;
     double z = 1.0 * uniform53(r.v[0]) + 1.0;
     z *= z;
@@ -114,25 +115,26 @@ MCD_HD ChainDraw chain_draw(uint64_t seed, int64_t step, int h, int64_t b, int64
     d.thr = det_log(uniform53(r.v[1])) - (double)(n_dim - 1) * det_log(z);
     int64_t p = (int64_t)(uniform53(r.v[2]) * (double)half);
     d.pick = (int32_t)(p < half ? p : half - 1);
+    d.order_key = ((r.v[3] >> kOrderKeyShift) << kOrderKeyShift) | (uint64_t)((int64_t)h * half + j);
     return d;
 }
 
 // Host: the numbers of ONE step in the layout mcd_stretch_move takes for a block of one step: order [B][W], zz / thr / pick
-// [2][B][W/2].  The split = stable argsort of the keys (ties by walker index), what the step kernel's rank-by-counting gives.
+// [2][B][W/2].
 inline void chain_numbers_of_step(uint64_t seed, int64_t step, int64_t B, int64_t W, int n_dim, int32_t* order, double* zz,
-                                  double* thr, int32_t* pick, std::vector<std::pair<double, int32_t>>& sorter) {
+                                  double* thr, int32_t* pick, std::vector<uint64_t>& sorter) {
     const int64_t half = W / 2;
     sorter.resize((size_t)W);
     for (int64_t b = 0; b < B; ++b) {
-        for (int64_t w = 0; w < W; ++w) sorter[(size_t)w] = std::make_pair(chain_order_key(seed, step, b, w), (int32_t)w);
-        std::sort(sorter.begin(), sorter.end());                       // (key, walker): ties by walker index
-        for (int64_t x = 0; x < W; ++x) order[b * W + x] = sorter[(size_t)x].second;
         for (int h = 0; h < 2; ++h)
             for (int64_t j = 0; j < half; ++j) {
                 const ChainDraw cd = chain_draw(seed, step, h, b, j, half, n_dim);
                 const int64_t at = ((int64_t)h * B + b) * half + j;
                 zz[at] = cd.z; thr[at] = cd.thr; pick[at] = cd.pick;
+                sorter[(size_t)(h * half + j)] = cd.order_key;
             }
+        std::sort(sorter.begin(), sorter.end());                       // (distinct: the walker index is part of the key)
+        for (int64_t x = 0; x < W; ++x) order[b * W + x] = (int32_t)(sorter[(size_t)x] & (((uint64_t)1 << kOrderKeyShift) - 1));
     }
 }
 

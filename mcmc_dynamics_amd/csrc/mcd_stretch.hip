@@ -240,8 +240,6 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
     __shared__ double s_lo[kMaxCols], s_hi[kMaxCols], s_const[kMaxCols], s_factor[kMaxCols];
     __shared__ int s_source[kMaxCols];
     __shared__ double s_rows[kStepBlock][kMaxCols + 1];        // (+1: rows of different threads start in different banks)
-    __shared__ double s_keys[2 * kStepBlock];                  // seeded blocks: the step's ordering keys and the split they give
-    __shared__ int s_order[2 * kStepBlock];
     double* const s_pos = s_dynamic;
     double* const s_lnp = s_dynamic + W * P;
     int* const s_second = reinterpret_cast<int*>(s_lnp + W);
@@ -279,13 +277,8 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
         if (active) {
             ok_prev = ok_b[j] != 0;
             if constexpr (!kFused) ll_j = ll_b[j];
-            if (d.seeded) {
-                w_acc = d.order_scratch[b * W + (acc_h == 0 ? 0 : half) + j];
-                thr_j = d.thr_scratch[((int64_t)acc_h * B + b) * half + j];
-            } else {
-                w_acc = d.order[(acc_step * B + b) * W + (acc_h == 0 ? 0 : half) + j];
-                thr_j = d.thr[((acc_step * 2 + acc_h) * B + b) * half + j];
-            }
+            w_acc = d.order[(acc_step * B + b) * W + (acc_h == 0 ? 0 : half) + j];
+            thr_j = d.thr[((acc_step * 2 + acc_h) * B + b) * half + j];
 #pragma unroll
             for (int c = 0; c < kMaxCols; ++c) prev[c] = c < P ? proposal_b[j * P + c] : 0.0;
         }
@@ -301,15 +294,11 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
     }
     int w_s = 0, pick_j = 0;
     double z_j = 0.0;
-    if (do_prop && active && !d.seeded) {
+    if (do_prop && active) {
         w_s = d.order[(prop_step * B + b) * W + (prop_h == 0 ? 0 : half) + j];
         s_second[j] = d.order[(prop_step * B + b) * W + (prop_h == 0 ? half : 0) + j];
         pick_j = d.pick[((prop_step * 2 + prop_h) * B + b) * half + j];
         z_j = d.zz[((prop_step * 2 + prop_h) * B + b) * half + j];
-    }
-    if (do_prop && active && d.seeded && prop_h == 1) {        // second half step: the split this step's first launch left
-        w_s = d.order_scratch[b * W + half + j];
-        s_second[j] = d.order_scratch[b * W + j];
     }
     if (do_prop && j < kMaxCols) {
         s_lo[j] = j < P ? d.lo[j] : 0.0;
@@ -370,35 +359,6 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
     }
     MCD_STAMP(2);
     if (!do_prop) return;
-    if (d.seeded) {
-        // ---- this half step's random numbers, generated here (mcd_rng.h): a function of (seed, step, half step, ensemble,
-        // walker / slot) alone.  First half step of a step: the split of the ensemble = argsort of one key per walker (ties by
-        // walker index), by counting -- every thread ranks its (at most two) walkers against all keys in LDS.
-        const int64_t step = d.step0 + prop_step;
-        if (prop_h == 0) {
-            for (int w = j; w < W; w += kStepBlock) s_keys[w] = chain_order_key(d.seed, step, b, w);
-            __syncthreads();
-            for (int w = j; w < W; w += kStepBlock) {
-                const double kw = s_keys[w];
-                int rank = 0;
-                for (int v = 0; v < W; ++v) {
-                    const double kv = s_keys[v];
-                    rank += (kv < kw || (kv == kw && v < w)) ? 1 : 0;
-                }
-                s_order[rank] = w;
-            }
-            __syncthreads();
-            for (int x = j; x < W; x += kStepBlock) d.order_scratch[b * W + x] = s_order[x];
-            if (active) { w_s = s_order[j]; s_second[j] = s_order[half + j]; }
-        }
-        if (active) {
-            const ChainDraw cd = chain_draw(d.seed, step, prop_h, b, j, half, P);
-            z_j = cd.z;
-            pick_j = cd.pick;
-            d.thr_scratch[((int64_t)prop_h * B + b) * half + j] = cd.thr;
-        }
-        __syncthreads();                                       // (s_second is complete before the partner look-ups)
-    }
     // ---- propose ----
     bool good = false;
     double mine_prop[kMaxCols];
@@ -496,6 +456,43 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
     MCD_STAMP(7);
 }
 
+// ---- seeded blocks (mcd_stretch_move_seeded): the random numbers of steps [i0, i1) of a block, written where the host's
+// upload would have put them (order [i][B][W], zz / thr / pick [i][2][B][W/2]) -- the step kernels do not know the difference.
+// One workgroup per (ensemble, step): one generator call per walker (mcd_rng.h: chain_draw), the split of the ensemble by
+// counting -- every thread ranks its walkers' keys against all keys in LDS, one unsigned comparison per pair (the keys are
+// distinct: the walker index is their low bits).  A block of 256 steps x 55 ensembles x 512 walkers is 14 080 workgroups of
+// ~10 us: ~0.1 ms next to 40 ms of likelihood kernels, on a stream of its own.
+constexpr int kNumbersBlock = 256;
+__global__ __launch_bounds__(kNumbersBlock) void chain_numbers_kernel(uint64_t seed, int64_t step0, int64_t i0, int64_t B,
+                                                                      int64_t W, int n_dim, int32_t* __restrict__ order,
+                                                                      double* __restrict__ zz, double* __restrict__ thr,
+                                                                      int32_t* __restrict__ pick) {
+    extern __shared__ unsigned long long s_order_keys[];                // [W]
+    const int64_t b = blockIdx.x, i = i0 + blockIdx.y, half = W / 2;
+    const int t = threadIdx.x;
+    for (int64_t w = t; w < W; w += kNumbersBlock) {
+        const int h = w >= half ? 1 : 0;
+        const int64_t j = w - h * half;
+        const ChainDraw cd = chain_draw(seed, step0 + i, h, b, j, half, n_dim);
+        const int64_t at = ((i * 2 + h) * B + b) * half + j;
+        zz[at] = cd.z;
+        thr[at] = cd.thr;
+        pick[at] = cd.pick;
+        s_order_keys[w] = cd.order_key;
+    }
+    __syncthreads();
+    const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(s_order_keys);       // (W is even)
+    for (int64_t w = t; w < W; w += kNumbersBlock) {
+        const unsigned long long mine = s_order_keys[w];
+        int rank = 0;
+        for (int64_t v = 0; v < half; ++v) {
+            const ulonglong2 k = pairs[v];                               // every lane reads the same address: a broadcast
+            rank += (k.x < mine ? 1 : 0) + (k.y < mine ? 1 : 0);
+        }
+        order[(i * B + b) * W + rank] = (int32_t)w;
+    }
+}
+
 // status word -> a double every rank can sum (multi-rank: ranks hold different catalogue statistics, so their guard
 // verdicts may differ; all of them must discard the block if one does)
 __global__ void stretch_status_kernel(const int32_t* meta, double* out) { out[0] = meta[META_STATUS] != 0 ? 1.0 : 0.0; }
@@ -529,7 +526,7 @@ hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t ac
             hipLaunchKernelGGL((stretch_step_small_kernel<C, BINNED, false>), dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, \
                                s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);                                       \
     } while (0)
-    if ((d.fused || d.seeded) && !small) return hipErrorInvalidValue;
+    if (d.fused && !small) return hipErrorInvalidValue;
     const bool binned = d.n_bins > 1;
     if (small && cols <= 4) { if (binned) MCD_LAUNCH_SMALL(4, true); else MCD_LAUNCH_SMALL(4, false); }
     else if (small && cols <= 8) { if (binned) MCD_LAUNCH_SMALL(8, true); else MCD_LAUNCH_SMALL(8, false); }
@@ -537,6 +534,19 @@ hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t ac
 #undef MCD_LAUNCH_SMALL
     else
         hipLaunchKernelGGL(stretch_step_kernel, dim3(1), dim3(kStepBlock), 0, s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);
+    return hipGetLastError();
+}
+
+bool chain_numbers_on_device(int64_t n_walkers) { return n_walkers * 8 <= (64 << 10) && n_walkers <= kSeededMaxWalkers; }
+
+hipError_t launch_chain_numbers(hipStream_t s, uint64_t seed, int64_t step0, int64_t i0, int64_t i1, int64_t n_bins,
+                                int64_t n_walkers, int n_dim, int32_t* order, double* zz, double* thr, int32_t* pick) {
+    if (!chain_numbers_on_device(n_walkers) || n_bins < 1 || n_bins > 0x7fffffff) return hipErrorInvalidValue;
+    for (int64_t at = i0; at < i1; at += 65535) {                        // (gridDim.y <= 65535)
+        const int64_t n = i1 - at < 65535 ? i1 - at : 65535;
+        hipLaunchKernelGGL(chain_numbers_kernel, dim3((unsigned)n_bins, (unsigned)n), dim3(kNumbersBlock),
+                           (size_t)n_walkers * 8, s, seed, step0, at, n_bins, n_walkers, n_dim, order, zz, thr, pick);
+    }
     return hipGetLastError();
 }
 

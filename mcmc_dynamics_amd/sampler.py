@@ -39,7 +39,7 @@ class EnsembleSampler(object):
     def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, a=2.0, vectorize=False, seed=None, block_fn=None, rng="host",
                  seeded_block_fn=None):
         """``rng="device"``: the move's random numbers come from the counter-based generator of csrc/mcd_rng.h instead of
-        NumPy's Mersenne twister -- a function of (seed, step, half step, walker) alone, generated inside the step kernel by
+        NumPy's Mersenne twister -- a function of (seed, step, half step, walker) alone, generated on the device (csrc/mcd_stretch.hip: chain_numbers_kernel) by
         ``seeded_block_fn`` (``Runner._stretch_block_seeded``), or taken from ``_native.chain_numbers`` by the Python loop
         below when there is none: the same chain either way, and however it is cut into blocks."""
         if rng not in ("host", "device"):
@@ -200,7 +200,7 @@ class EnsembleSampler(object):
         if device_rng and self.seeded_block_fn is None:
             from . import _native as native
 
-            def draw(block):                                 # noqa: F811 -- the same numbers the step kernel generates
+            def draw(block):                                 # noqa: F811 -- the same numbers the device generates
                 order_b, zz_b, thr_b, pick_b = native.chain_numbers(self.seed64, self.iteration, block, 1, self.nwalkers,
                                                                     self.ndim, squeeze=True)
                 return order_b.astype(np.int64), zz_b, thr_b, pick_b

@@ -289,12 +289,12 @@ extern "C" void emul_det_log(int64_t n, const double* x, double* out) {
 }
 extern "C" void emul_chain_numbers(uint64_t seed, int64_t step0, int64_t n_steps, int64_t B, int64_t W, int n_dim,
                                    int32_t* order, double* zz, double* thr, int32_t* pick) {
-    std::vector<std::pair<double, int32_t>> sorter;
+    std::vector<uint64_t> sorter;
     const int64_t half = W / 2;
     for (int64_t i = 0; i < n_steps; ++i)
         chain_numbers_of_step(seed, step0 + i, B, W, n_dim, order + i * B * W, zz + i * 2 * B * half, thr + i * 2 * B * half,
                               pick + i * 2 * B * half, sorter);
 }
-extern "C" void emul_chain_keys(uint64_t seed, int64_t step, int64_t b, int64_t W, double* out) {
-    for (int64_t w = 0; w < W; ++w) out[w] = chain_order_key(seed, step, b, w);
+extern "C" void emul_chain_keys(uint64_t seed, int64_t step, int64_t b, int64_t W, uint64_t* out) {
+    for (int64_t w = 0; w < W; ++w) out[w] = chain_draw(seed, step, (int)(w / (W / 2)), b, w % (W / 2), W / 2, 1).order_key >> kOrderKeyShift;
 }

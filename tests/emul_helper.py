@@ -288,7 +288,8 @@ def chain_numbers(seed, step0, n_steps, n_bins, n_walkers, n_dim):
 
 
 def chain_keys(seed, step, b, n_walkers):
-    out = np.empty(int(n_walkers))
+    """The 44-bit ordering keys of the walkers of ensemble b in one step."""
+    out = np.empty(int(n_walkers), dtype=np.uint64)
     L = lib()
     L.emul_chain_keys.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
     L.emul_chain_keys.restype = None

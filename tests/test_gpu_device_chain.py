@@ -451,14 +451,16 @@ def run_seeded(cat, plan, pos, lnp, seed, step0, n_steps, device):
     return pos, lnp, chain, lnpc, acc
 
 
-@pytest.mark.parametrize("model,free,w", [(0, False, 48), (0, False, 512), (2, True, 64), (5, False, 130)])
+@pytest.mark.parametrize("model,free,w", [(0, False, 48), (0, False, 512), (2, True, 64), (5, False, 130), (0, False, 8200)])
 def test_seeded_blocks_generate_their_numbers_on_the_device(native, ctx, model, free, w):
-    """`mcd_stretch_move_seeded`: the step kernel generates the block's random numbers (csrc/mcd_rng.h) -- against (a) the
-    host-driven block of the same call (numbers generated on the host by the same functions), (b) `mcd_stretch_move` fed
-    with `mcd_chain_numbers` of the same (seed, steps), resident and host-driven, (c) the same steps cut into two calls:
-    every bit equal.  512 walkers: two walkers per thread in the ranking of the ordering keys; 130: a ragged last wave."""
+    """`mcd_stretch_move_seeded`: a kernel generates the block's random numbers on the device (csrc/mcd_rng.h,
+    mcd_stretch.hip: chain_numbers_kernel) -- against (a) the host-driven block of the same call (numbers generated on the
+    host by the same functions), (b) `mcd_stretch_move` fed with `mcd_chain_numbers` of the same (seed, steps), resident and
+    host-driven, (c) the same steps cut into two calls: every bit equal.  512 walkers: two walkers per thread in the ranking
+    of the ordering keys; 130: a ragged last wave; 8200: more ordering keys than the kernel keeps in LDS -- the host build
+    fills the block's numbers, uploaded as usual."""
     rng = np.random.default_rng(9700 + 10 * model + free + w)
-    cat, sv = _catalogue(native, ctx, rng, 30011, model, free)
+    cat, sv = _catalogue(native, ctx, rng, 30011 if w < 1000 else 3011, model, free)
     pos = _walkers(rng, w, model, sv, free)
     lo, hi = np.full(cat.k, -np.inf), np.full(cat.k, np.inf)
     lo[1] = 0.0
@@ -469,7 +471,7 @@ def test_seeded_blocks_generate_their_numbers_on_the_device(native, ctx, model, 
         lo[2] = lo[5] = 1.0
     plan = identity_plan(cat.k, lo, hi)
     lnp = cat.loglike(pos)
-    seed, step0, n = 0xC0FFEE1234567 + model, 1000, 17
+    seed, step0, n = 0xC0FFEE1234567 + model, 1000, 17 if w < 1000 else 7
     before = cat.stretch_info()
     dev = run_seeded(cat, plan, pos, lnp, seed, step0, n, device=1)
     mid = cat.stretch_info()
@@ -489,10 +491,10 @@ def test_seeded_blocks_generate_their_numbers_on_the_device(native, ctx, model, 
     assert 0 < dev[4].sum() < n * w and np.all(np.isfinite(dev[3]))
     other = run_seeded(cat, plan, pos, lnp, seed + 1, step0, n, device=1)
     assert not np.array_equal(other[2], dev[2])
-    # ensembles the in-LDS step kernel does not take (option 2: the general step kernel) are run host-driven: same chain
+    # the step kernel for ensembles of any size (option 2) reads the same generated numbers
     before = cat.stretch_info()
     assert same(dev, run_seeded(cat, plan, pos, lnp, seed, step0, n, device=2))
-    assert cat.stretch_info()["host_blocks"] == before["host_blocks"] + 1
+    assert cat.stretch_info()["device_blocks"] == before["device_blocks"] + 1
     cat.close()
 
 

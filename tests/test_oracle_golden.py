@@ -321,7 +321,7 @@ def test_builtin_stretch_move_samples_like_emcees_default_move():
         acc["builtin"].append(s.acceptance_fraction.mean())
         med["builtin"].append(np.median(flat, axis=0))
         std.append(flat.std(axis=0))
-        # ... and the same move with the counter-based random numbers of csrc/mcd_rng.h (rng="device": what the step kernel
+        # ... and the same move with the counter-based random numbers of csrc/mcd_rng.h (rng="device": what the device
         # generates for seeded blocks; here through the library's host entry point mcd_chain_numbers)
         s = EnsembleSampler(32, 4, lnprob, vectorize=True, seed=seed, rng="device")
         s.run_mcmc(pos, n_steps)
