@@ -47,6 +47,8 @@ timeout -k 10 300 python tools/fuzz_gpu.py --seconds 100 --schedule --max-walker
 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 > $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 MCD_CHAIN_PART_BYTES=1 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 7 >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 11 --force-rccl >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
+timeout -k 10 300 python tools/fuzz_chain.py --seconds 60 --seed 13 --seeded >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
+MCD_CHAIN_PART_BYTES=1 timeout -k 10 300 python tools/fuzz_chain.py --seconds 40 --seed 17 --seeded >> $O/fuzz_chain_$TAG.log 2>&1 || { tail -5 $O/fuzz_chain_$TAG.log; exit 1; }
 echo "kernel traces done"
 fi
 if [ "$STAGE" = all ] || [ "$STAGE" = c ]; then
