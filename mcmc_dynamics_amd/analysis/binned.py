@@ -307,7 +307,9 @@ class BinnedConstantFit(ConstantFit):
         if not np.all(np.isfinite(lp)):
             raise ValueError("Invalid initial guesses for {0} walker(s).".format(int(np.sum(~np.isfinite(lp)))))
         # box priors: whole blocks of steps inside the library (mcd_stretch_move with n_bins = B, Runner._stretch_block)
-        native_ok = self._plan().simple and self.n_bins > 1
+        # (library blocks only for the package's own posterior and box priors: a subclass that overrides a posterior method
+        # outside the package is driven by the NumPy loop around ITS lnprob_batch -- Runner.resident_ok)
+        native_ok = self.resident_ok()[0] and self.n_bins > 1
         sampler = BinnedSampler(self.n_bins, n_walkers, self.n_fitted_parameters, self.lnprob_batch, seed=seed,
                                 block_fn=self._stretch_block if native_ok else None, rng=rng or self.RNG,
                                 seeded_block_fn=self._stretch_block_seeded if native_ok else None)

@@ -532,3 +532,38 @@ def test_a_subclass_that_changes_the_posterior_is_never_run_inside_the_library(m
     assert Tilted.calls > 300
     flat = sampler.get_chain(discard=100, flat=True)
     assert np.all(np.abs(flat.mean(axis=0) - np.array([50.0, 3.0, -20.0, 20.0])) < 0.5)
+
+
+def test_a_binned_subclass_that_changes_the_posterior_gets_the_numpy_loop():
+    """The same rule for `BinnedConstantFit.__call__`: library blocks (host or device numbers) only for the package's own
+    posterior; an override outside the package is driven through ITS lnprob_batch, with the device generator's numbers
+    (`rng="device"`: `mcd_chain_numbers`, host code) -- no catalogue is ever built here."""
+    from mcmc_dynamics_amd.analysis import BinnedConstantFit
+    g = load_golden("radial_bins")
+    reader = DataReader({k: g[k] for k in ("ra", "dec", "v", "verr")})
+    reader.make_radial_bins(float(g["ra_center"]), float(g["dec_center"]), nstars=200, dlogr=0.05)
+
+    class Tilted(BinnedConstantFit):
+        calls = 0
+
+        def lnprob_batch(self, values):
+            Tilted.calls += 1
+            values = np.asarray(values, dtype=np.float64)
+            return -0.5 * np.sum((values - np.array([5.0, 3.0, -2.0, 2.0])) ** 2, axis=-1)
+
+    fit = Tilted(reader)
+    fit.parameters["ra_center"].set(value=float(g["ra_center"]), fixed=True)
+    fit.parameters["dec_center"].set(value=float(g["dec_center"]), fixed=True)
+    assert not fit.resident_ok()[0]
+    B = fit.n_bins
+    pos = np.array([5.0, 3.0, -2.0, 2.0]) + np.random.default_rng(2).normal(0, 1, size=(B, 16, 4))
+    pos[..., 1] = np.abs(pos[..., 1])
+    s = fit(n_walkers=16, n_steps=200, pos=pos, seed=3)
+    assert s.rng == "device" and s.block_fn is None and s.seeded_block_fn is None and Tilted.calls >= 400
+    assert fit._catalog is None
+    flat = s.chain[:, :, 80:].reshape(-1, 4)
+    assert np.all(np.abs(flat.mean(axis=0) - np.array([5.0, 3.0, -2.0, 2.0])) < 0.3)
+    again = fit(n_walkers=16, n_steps=200, pos=pos, seed=3)
+    assert np.array_equal(again.chain, s.chain)                        # reproducible from the seed
+    s.close()
+    again.close()
