@@ -298,6 +298,20 @@ double mcd_last_device_ms(const mcd_catalog* cat);
  *   "tail_split"    chunk schedule: 0 equal-length chunks; 1 (default): the last ~15 % of a large parameter set is
  *                      cut into half- and quarter-length chunks so that the launch ends on short waves; 2-4:
  *                      other guided schedules kept for tuning (see build_workset in mcd_api.hip)
+ *   "balance"       balanced single-round chunk plans for small catalogues (every workgroup of the launch resident at once,
+ *                      chunks of equal length: no tail, no second round): -1 (default) by work -- 2, 4 or 8 workgroups per
+ *                      CU below ~1e6 work units, the multi-round table beyond; 0 never; 1 .. 8 forced
+ *   "combine"       balanced plans run as 8- / 16-wave workgroups that add up their chunks' sums themselves (one partial
+ *                      sum per workgroup and walker instead of one per chunk): 1 (default) the largest the plan allows,
+ *                      0 never, 8 / 16 at most that many waves
+ *   "two_lanes"     1 (default): pipelined evaluations (mcd_loglike_enqueue back to back) alternate between two streams
+ *                      with their own partial-sum and result buffers, so that one launch's tail and reduction overlap
+ *                      the next launch's start; 0: one stream.  Results do not depend on it.
+ *   "fused_reduce"  1 (default): resident stretch-move blocks whose launches leave <= 256 partial sums per walker run
+ *                      without the reduction kernel (the step kernel adds them up, same code, same order); 0: never
+ *   "defer_guard"   1 (default): resident blocks of ONE ensemble judge the range guard of all their launches after the
+ *                      last step instead of between two main kernels (same verdicts, same discards); 0: in the step kernel
+ *   "f32_domain"    1 (default): float32 catalogues refuse parameter tables outside the float32 accuracy domain (below)
  * Returns MCD_ERR_INVALID for an unknown key. */
 int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value);
 /* With "timing" = 2: waits for the device, returns the summed HIP-event duration (ms) of all main-kernel

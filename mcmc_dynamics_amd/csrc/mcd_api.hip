@@ -249,6 +249,7 @@ struct mcd_catalog {
     // resident stretch-move chain (mcd_stretch.hip)
     int device_chain = 1;              // option "device_chain": 0 host-driven blocks only
     int fused_reduce = 1;              // option "fused_reduce": the step kernel adds up small launches' partial sums itself
+    int defer_guard = 1;               // option "defer_guard": one-ensemble resident blocks judge their tables at the end
     bool chain_last_fused = false;
     ChainArena chain;
     int chain_hint = -1;               // kernel family the device's guard asked for when it last disagreed (-1: none)
@@ -863,11 +864,13 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     if (cat->chain_backoff > 0) { --cat->chain_backoff; return MCD_OK; }
     const int64_t W = d->n_walkers, half = W / 2;
     const int P = d->n_dim, K = d->k;
+    bool small_ensemble = false;                                   // the step kernel that keeps the ensemble in LDS takes it
     {
         mcd::StretchDevice probe;
         probe.n_bins = B; probe.n_walkers = W; probe.n_dim = P; probe.k = K;
         probe.force_general = cat->device_chain == 2;
         if (!mcd::stretch_step_handles(probe)) return MCD_OK;
+        small_ensemble = mcd::stretch_step_fuses(probe);
     }
     Shard& sh = cat->shards[0];
     const DeviceSlot& slot = ctx->slots[sh.slot];
@@ -890,6 +893,11 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     const size_t BW = (size_t)B * W, Bh = (size_t)B * half;
     const size_t o_pos = take(BW * P * 8), o_lnp = take(BW * 8), o_acc = take(BW * 8);
     const size_t o_meta = take(mcd::META_WORDS * 4), o_status = take(8);
+    // deferred guard (one ensemble, the in-LDS step kernel; option "defer_guard"): every launch's table rows are kept and
+    // judged together at the end of the block (mcd_stretch.hip: stretch_judge_kernel) -- unless the log would be large
+    const size_t n_launches = (size_t)2 * n_steps;
+    const bool defer = cat->defer_guard != 0 && B == 1 && small_ensemble && n_launches * half * K * 8 <= ((size_t)64 << 20);
+    const size_t o_levels = take(defer ? n_launches * 4 : 0);
     const size_t state_end = off;
     const size_t o_src = take((size_t)K * 4), o_const = take((size_t)K * 8), o_fac = take((size_t)K * 8);
     const size_t o_lo = take((size_t)P * 8), o_hi = take((size_t)P * 8);
@@ -902,6 +910,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     const size_t o_thr = take(n_in * BW * 8), o_pick = take(n_in * BW * 4);
     const size_t input_end = off;
     const size_t o_prop = take(Bh * P * 8), o_ok = take(Bh), o_nok = take((size_t)2 * B * 4), o_ranges = take((size_t)2 * B * 10 * 8);
+    const size_t o_nok_log = take(defer ? n_launches * 4 : 0), o_table_log = take(defer ? n_launches * half * K * 8 : 0);
     const size_t o_chain = take(chain ? (size_t)n_steps * BW * P * 8 : 0);
     const size_t o_lnpc = take(lnprob_chain ? (size_t)n_steps * BW * 8 : 0);
     const size_t total = off;
@@ -1002,6 +1011,10 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     sd.proposal = (double*)(a.d + o_prop); sd.ok = (uint8_t*)(a.d + o_ok); sd.meta = (int32_t*)(a.d + o_meta);
     sd.n_ok = (int32_t*)(a.d + o_nok); sd.ranges = (double*)(a.d + o_ranges);
     sd.table = w.d_params; sd.wpar = (double*)w.d_wpar;
+    if (defer) {
+        sd.defer_guard = 1;
+        sd.table_log = (double*)(a.d + o_table_log); sd.n_ok_log = (int32_t*)(a.d + o_nok_log); sd.level_log = (int32_t*)(a.d + o_levels);
+    }
 
     const bool coll = ctx->n_ranks > 1 || ctx->force_collective;
     mcd::LaunchShape shape{cat->model, cat->free_centre, cat->precision, level, w.uniform_len, sh.n};
@@ -1063,6 +1076,7 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
     };
     auto finish = [&]() -> int {                               // the last accept [+ the collective status word]
         MCD_HIP(mcd::launch_stretch_step(slot.stream, sd, acc_step, acc_h, -1, 0, out_buf, prev_tag));
+        if (defer) MCD_HIP(mcd::launch_stretch_judge(slot.stream, sd, (int64_t)n_launches));
         if (coll) {
             // ranks hold different shares of the catalogue, so their guard verdicts may differ: all discard the block if one does
             double* status = (double*)(a.d + o_status);
@@ -1201,6 +1215,12 @@ int stretch_block_device(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_
         ++cat->chain_discarded;
         cat->chain_last_status = meta[mcd::META_STATUS];
         cat->chain_hint = (meta[mcd::META_STATUS] & mcd::CHAIN_LEVEL) ? meta[mcd::META_LEVEL] : -1;
+        if (defer && (meta[mcd::META_STATUS] & mcd::CHAIN_LEVEL)) {      // the first launch whose verdict differed
+            const int32_t* levels = (const int32_t*)(a.h + o_levels);
+            cat->chain_hint = -1;
+            for (size_t l = 0; l < n_launches; ++l)
+                if (levels[l] >= 0 && levels[l] != level) { cat->chain_hint = levels[l]; break; }
+        }
         // every rank of a job counts the same discards (the verdict above is collective), so the back-off stays in step
         cat->chain_consecutive = std::min(cat->chain_consecutive + 1, 7);
         cat->chain_backoff = cat->chain_consecutive > 1 ? ((int64_t)1 << (cat->chain_consecutive - 1)) : 0;
@@ -1807,6 +1827,7 @@ int mcd_set_option(mcd_catalog* cat, const char* key, int64_t value) {
         return MCD_OK;
     }
     if (!std::strcmp(key, "fused_reduce")) { cat->fused_reduce = value != 0; return MCD_OK; }
+    if (!std::strcmp(key, "defer_guard")) { cat->defer_guard = value != 0; return MCD_OK; }
     if (!std::strcmp(key, "f32_domain")) { cat->f32_domain = value != 0; return MCD_OK; }
     if (!std::strcmp(key, "two_lanes")) {
         int rc = sync_all(cat);

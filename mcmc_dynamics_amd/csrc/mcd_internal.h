@@ -111,12 +111,19 @@ struct StretchDevice {
     int32_t* n_ok = nullptr;               // [2][B] proposals inside the prior, per ensemble and half-step parity
     double* ranges = nullptr;              // [2][B][10] ParamRanges of each ensemble's table (B > 1: judged by the next launch)
     double* table = nullptr;               // [W/2][k]   resolved parameter rows (the guard reads them back)
+    // deferred guard (ONE ensemble, the in-LDS step kernel): the step kernel logs each launch's rows and the number of
+    // proposals inside the prior; stretch_judge_kernel gives all verdicts at the end of the block (mcd_stretch.hip)
+    int32_t defer_guard = 0;
+    double* table_log = nullptr;           // [2 n_steps][W/2][k]
+    int32_t* n_ok_log = nullptr;           // [2 n_steps]
+    int32_t* level_log = nullptr;          // [2 n_steps]  verdict per launch, -1 where there was no table
     double* wpar = nullptr;                // [W/2][KD]  derived walker constants: what the main kernel reads
 };
 
 hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t acc_step, int acc_h, int64_t prop_step,
                                int prop_h, const double* ll, double rerun_tag);
 hipError_t launch_stretch_status(hipStream_t s, const int32_t* meta, double* out);
+hipError_t launch_stretch_judge(hipStream_t s, const StretchDevice& d, int64_t n_launches);
 // seeded blocks: the numbers of steps [i0, i1) of a block generated on the device, in the layout of the host's upload
 // (mcd_rng.h); ensembles whose keys do not fit in LDS get their numbers from the host build of the same functions
 bool chain_numbers_on_device(int64_t n_walkers);

@@ -402,6 +402,12 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
     }
     __syncthreads();
     MCD_STAMP(4);
+    // One ensemble with the guard deferred (d.defer_guard): the resolved rows go to this launch's place in the table log and
+    // stretch_judge_kernel gives the verdicts of all launches at the end of the block -- the verdict only decides whether the
+    // block is kept, so the range reduction, its barrier and the verdict (1.9 of 7 us) need not sit between two main kernels.
+    const bool defer = !kBinned && d.defer_guard != 0;
+    const int64_t launch = prop_step * 2 + prop_h;
+    double* const table_rows = defer ? d.table_log + launch * half * K : d.table + b * half * K;
     ParamRanges mine;
     if (active && n_ok > 0) {
         // a row outside the prior takes the first valid row's place in the launch and is masked when the sums come back
@@ -418,12 +424,22 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
 #pragma unroll
         for (int c = 0; c < kMaxCols; ++c) {
             row[c] = resolved[c];
-            if (c < K) d.table[(b * half + j) * K + c] = resolved[c];
+            if (c < K) table_rows[j * K + c] = resolved[c];
         }
         walker_constants<double>(row, d.model, d.free_centre != 0, d.wpar + (b * half + j) * KD);
-        mine.add_row(row, K, d.model, d.free_centre != 0);
+        if (!defer) mine.add_row(row, K, d.model, d.free_centre != 0);
     }
     MCD_STAMP(5);
+    if (defer) {
+        if (j == 0) {
+            d.n_ok[slot_prop + b] = n_ok;
+            d.n_ok_log[launch] = n_ok;
+            if (n_ok == 0) atomicOr(&d.meta[META_STATUS], CHAIN_NO_PROPOSAL);
+        }
+        MCD_STAMP(6);
+        MCD_STAMP(7);
+        return;
+    }
     wave_merge_for(mine, d.model);
     if ((j & 63) == 0) store_ranges(mine, s_ranges[j >> 6]);
     __syncthreads();
@@ -454,6 +470,41 @@ __global__ __launch_bounds__(kFused ? kFusedThreads : kStepBlock) void stretch_s
         }
     }
     MCD_STAMP(7);
+}
+
+// The deferred guard of one-ensemble blocks: workgroup l judges the table of launch l (the rows the step kernel logged) with
+// the step kernel's own operations -- ranges of the rows, merged (minima and maxima: any order gives the same bits), the
+// verdict against the kernel family the block was enqueued with.  level_log[l] = the verdict, or -1 where the launch had no
+// proposal inside the prior (no table); the host takes the first launch whose verdict differs as the next block's hint.
+__global__ __launch_bounds__(kStepBlock) void stretch_judge_kernel(StretchDevice d) {
+    __shared__ double s_rows[kStepBlock][13];
+    __shared__ double s_ranges[kStepBlock / 64][10];
+    const int64_t launch = blockIdx.x;
+    const int j = threadIdx.x, half = (int)(d.n_walkers / 2), K = d.k;
+    const int n_ok = d.n_ok_log[launch];                                 // (workgroup-uniform)
+    if (n_ok <= 0) {
+        if (j == 0) d.level_log[launch] = -1;
+        return;
+    }
+    ParamRanges mine;
+    if (j < half) {
+        for (int c = 0; c < K; ++c) s_rows[j][c] = d.table_log[(launch * half + j) * K + c];
+        mine.add_row(s_rows[j], K, d.model, d.free_centre != 0);
+    }
+    wave_merge_for(mine, d.model);
+    if ((j & 63) == 0) store_ranges(mine, s_ranges[j >> 6]);
+    __syncthreads();
+    if (j == 0) {
+        ParamRanges all = load_ranges(s_ranges[0]);
+        for (int i = 1; i < kStepBlock / 64; ++i) all.merge(load_ranges(s_ranges[i]));
+        int level = 0;
+        if (d.allow_fast) {
+            level = level_verdict(d.stats, d.model, false, half, all);
+            if (d.allow_fast == 2 && level > 1) level = 1;
+        }
+        d.level_log[launch] = level;
+        if (level != d.expected_level) atomicOr(&d.meta[META_STATUS], CHAIN_LEVEL);
+    }
 }
 
 // ---- seeded blocks (mcd_stretch_move_seeded): the random numbers of steps [i0, i1) of a block, written where the host's
@@ -526,7 +577,7 @@ hipError_t launch_stretch_step(hipStream_t s, const StretchDevice& d, int64_t ac
             hipLaunchKernelGGL((stretch_step_small_kernel<C, BINNED, false>), dim3((unsigned)d.n_bins), dim3(kStepBlock), lds, \
                                s, d, acc_step, acc_h, prop_step, prop_h, ll, rerun_tag);                                       \
     } while (0)
-    if (d.fused && !small) return hipErrorInvalidValue;
+    if ((d.fused || d.defer_guard) && (!small || (d.defer_guard && d.n_bins != 1))) return hipErrorInvalidValue;
     const bool binned = d.n_bins > 1;
     if (small && cols <= 4) { if (binned) MCD_LAUNCH_SMALL(4, true); else MCD_LAUNCH_SMALL(4, false); }
     else if (small && cols <= 8) { if (binned) MCD_LAUNCH_SMALL(8, true); else MCD_LAUNCH_SMALL(8, false); }
@@ -547,6 +598,12 @@ hipError_t launch_chain_numbers(hipStream_t s, uint64_t seed, int64_t step0, int
         hipLaunchKernelGGL(chain_numbers_kernel, dim3((unsigned)n_bins, (unsigned)n), dim3(kNumbersBlock),
                            (size_t)n_walkers * 8, s, seed, step0, at, n_bins, n_walkers, n_dim, order, zz, thr, pick);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_stretch_judge(hipStream_t s, const StretchDevice& d, int64_t n_launches) {
+    if (!d.defer_guard || !stretch_step_fuses(d) || d.n_bins != 1 || n_launches < 1 || n_launches > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stretch_judge_kernel, dim3((unsigned)n_launches), dim3(kStepBlock), 0, s, d);
     return hipGetLastError();
 }
 

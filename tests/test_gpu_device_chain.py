@@ -210,22 +210,32 @@ def test_blocks_the_device_gives_back(native, ctx):
     cat.close()
 
     # (4) the kernel family changes inside a block: |v_sys| of the proposals crosses the narrow-range bound
-    # d_max^2 <= 2e6 n_min (mcd_guard.h), so some half steps want level 2 and some level 1
+    # d_max^2 <= 2e6 n_min (mcd_guard.h), so some half steps want level 2 and some level 1.  With the guard deferred to the
+    # end of the block (option "defer_guard", the default: mcd_stretch.hip: stretch_judge_kernel) and judged launch by launch
+    # inside the step kernel: the same blocks discarded, the same kernel family picked for the next block, the same chains.
     cat, sv = _catalogue(native, ctx, rng, 5000, 1, False)
     pos = _walkers(rng, w, 1, sv, False)
     pos[:, 1] = rng.uniform(0.05, 0.2, w)                             # n_min ~ verr_min^2 = 0.25: bound at d_max ~ 707
     pos[:, 0] = rng.uniform(300.0, 640.0, w)
     lnp = cat.loglike(pos)
     plan = identity_plan(4, lo=[-np.inf, 0.0, -np.inf, -np.inf])
-    levels = set()
-    for trial in range(6):
-        randoms = block_randoms(rng, 8, w, 4)
-        dev = run_block(cat, plan, pos, lnp, randoms, device=True)
-        host = run_block(cat, plan, pos, lnp, randoms, device=False)
-        assert same(dev, host), trial
-        levels.add(cat.fast_level)
-    info = cat.stretch_info()
-    assert info["discarded_blocks"] >= 1 and info["last_discard_status"] & 4, info
+    blocks = [block_randoms(rng, 8, w, 4) for _ in range(6)]
+    history = {}
+    for defer in (1, 0):
+        cat.set_option("defer_guard", defer)
+        cat.loglike(pos)                                               # (both passes start from the same kernel-family hint)
+        seen, before = [], cat.stretch_info()
+        for trial, randoms in enumerate(blocks):
+            dev = run_block(cat, plan, pos, lnp, randoms, device=True)
+            info = cat.stretch_info()
+            seen.append((cat.fast_level, info["discarded_blocks"] - before["discarded_blocks"], info["last_discard_status"], dev))
+            host = run_block(cat, plan, pos, lnp, randoms, device=False)
+            assert same(dev, host), (defer, trial)
+        history[defer] = seen
+        info = cat.stretch_info()
+        assert info["discarded_blocks"] > before["discarded_blocks"] and info["last_discard_status"] & 4, (defer, info)
+    for a, b in zip(history[1], history[0]):
+        assert a[:3] == b[:3] and same(a[3], b[3]), (a[:3], b[:3])
     cat.close()
 
     # (2) re-run request of the fast mixture kernels: certain members that are gross outliers (denormal regime)

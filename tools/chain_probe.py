@@ -40,9 +40,10 @@ def randoms(k):
     return order, zz, thr, rng.integers(0, half, size=(k, 2, half)).astype(np.int32)
 
 
-for device, fused in ((1, 1), (0, 1), (1, 0), (1, 1)):
+for device, fused, defer in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0), (1, 1, 1)):
     g.set_option("device_chain", device)
     g.set_option("fused_reduce", fused)
+    g.set_option("defer_guard", defer)
     p, l = pos.copy(), lnp.copy()
     g.stretch_move(plan, p, l, *randoms(8))                      # warm: buffers, clocks
     best = 1e9
@@ -51,5 +52,5 @@ for device, fused in ((1, 1), (0, 1), (1, 0), (1, 1)):
         t0 = time.perf_counter()
         g.stretch_move(plan, p, l, *r)
         best = min(best, time.perf_counter() - t0)
-    print("device_chain {0} fused_reduce {4}: {1:7.1f} us per step ({2:.0f} steps/s), info {3}".format(
-        device, best / steps * 1e6, steps / best, g.stretch_info(), fused), flush=True)
+    print("device_chain {0} fused_reduce {4} defer_guard {5}: {1:7.1f} us per step ({2:.0f} steps/s), info {3}".format(
+        device, best / steps * 1e6, steps / best, g.stretch_info(), fused, defer), flush=True)
