@@ -616,14 +616,16 @@ def main():
             dt_host = timed_chain()
             fit_cat.set_option("device_chain", 1)
             mcmc["host_driven_steps_per_s"] = n_mcmc / dt_host
-            # the same blocks with the random numbers generated on the device (Runner.RNG = "device", csrc/mcd_rng.h)
+            # the default draws the move's numbers on the device (Runner.RNG = "device", csrc/mcd_rng.h); beside it the same
+            # blocks with NumPy's generator on the host (RNG = "host")
+            mcmc["random_numbers"] = "rng=" + getattr(sampler, "rng", "emcee")
             from mcmc_dynamics_amd.sampler import EnsembleSampler
-            dev_sampler = EnsembleSampler(n_walkers, fit.n_fitted_parameters, fit.lnprob_batch, vectorize=True, seed=3,
-                                          rng="device", seeded_block_fn=fit._stretch_block_seeded)
-            dev_state = dev_sampler.run_mcmc(start, 300)
+            host_sampler = EnsembleSampler(n_walkers, fit.n_fitted_parameters, fit.lnprob_batch, vectorize=True, seed=3,
+                                           rng="host", block_fn=fit._stretch_block)
+            host_state = host_sampler.run_mcmc(start, 300)
             t2 = time.perf_counter()
-            dev_sampler.run_mcmc(dev_state[0], n_mcmc, log_prob0=dev_state[1])
-            mcmc["device_rng_steps_per_s"] = n_mcmc / (time.perf_counter() - t2)
+            host_sampler.run_mcmc(host_state[0], n_mcmc, log_prob0=host_state[1])
+            mcmc["host_numbers_steps_per_s"] = n_mcmc / (time.perf_counter() - t2)
         fit.close()
 
     if world == 1 and n_bins > 1 and not args.no_mcmc and model == "const" and args.precision == "f64":

@@ -420,10 +420,12 @@ class Runner(object):
                                block_fn=self._stretch_block if resident else None, rng=self.RNG,
                                seeded_block_fn=self._stretch_block_seeded if resident else None)
 
-    # the built-in move's random numbers: "host" -- NumPy's Mersenne twister, drawn on the host as emcee does; "device" --
-    # the counter-based generator of csrc/mcd_rng.h in a kernel of its own (a function of (seed, step, walker): no numbers
-    # cross PCIe, the chain does not depend on how it is cut into blocks)
-    RNG = "host"
+    # the built-in move's random numbers: "device" (default) -- the counter-based generator of csrc/mcd_rng.h, generated on
+    # the device for resident blocks and by the library's host code for the Python loop (a function of (seed, step, walker):
+    # no numbers cross PCIe, the chain does not depend on how it is run or cut into blocks); "host" -- NumPy's Mersenne
+    # twister, drawn on the host as emcee does (the draws of 256 walkers then bound small catalogues: 26 000 steps/s at 1e5
+    # stars against 30 000).  emcee itself, when it drives (SAMPLER), draws as it always does.
+    RNG = "device"
     NATIVE_STRETCH = True          # sub-classes whose posterior is not ONE un-binned catalogue switch this off
 
     def _stretch_plan(self):

@@ -226,17 +226,19 @@ def deadline(kind):
                 fit.lnprob_batch(pos)
         else:
             calls = {"n": 0}
-            inner = fit._stretch_block
 
-            def flaky(*args):
-                calls["n"] += 1
-                if rank == 1 and calls["n"] == 2:
-                    if kind == "die":
-                        sys.stdout.flush()
-                        os._exit(9)
-                    raise RuntimeError("injected failure inside block 2 on rank 1")
-                return inner(*args)
-            fit._stretch_block = flaky
+            def flaky_version_of(inner):
+                def flaky(*args):
+                    calls["n"] += 1
+                    if rank == 1 and calls["n"] == 2:
+                        if kind == "die":
+                            sys.stdout.flush()
+                            os._exit(9)
+                        raise RuntimeError("injected failure inside block 2 on rank 1")
+                    return inner(*args)
+                return flaky
+            fit._stretch_block = flaky_version_of(fit._stretch_block)                  # (Runner.RNG = "host")
+            fit._stretch_block_seeded = flaky_version_of(fit._stretch_block_seeded)    # (the default: numbers from the device)
             fit.SAMPLER = "builtin"
             import mcmc_dynamics_amd.sampler as sampler_mod
             orig_init = sampler_mod.EnsembleSampler.__init__

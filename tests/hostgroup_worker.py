@@ -56,6 +56,13 @@ class ShardCatalog(object):
                                     ptr(accepted, ctypes.c_int64), cb)
         assert rc == 0
 
+    def stretch_move_seeded(self, plan, pos, lnp, seed, step0, n_steps, chain=None, lnprob_chain=None, accepted=None):
+        """`_native.Catalog.stretch_move_seeded`: the numbers of the host build of csrc/mcd_rng.h, then the block above."""
+        import emul_helper
+        order, zz, thr, pick = emul_helper.chain_numbers(seed, step0, n_steps, 1, pos.shape[0], pos.shape[1])
+        self.stretch_move(plan, pos, lnp, np.ascontiguousarray(order[:, 0]), np.ascontiguousarray(zz[:, :, 0]),
+                          np.ascontiguousarray(thr[:, :, 0]), np.ascontiguousarray(pick[:, :, 0]), chain, lnprob_chain, accepted)
+
     def close(self):
         pass
 

@@ -190,16 +190,19 @@ def test_library_stretch_move_equals_the_python_loop(case):
     assert fit.fitted_parameters == names
     pos = synthetic.make_walkers(32, names, cat["truth"], config=3)
     pos[:, names.index("sigma_max")] = np.abs(pos[:, names.index("sigma_max")] * (1.0 + 0.5 * np.random.default_rng(1).normal(size=32)))
-    native = fit._make_sampler(32, seed=11)
-    assert isinstance(native, EnsembleSampler) and native.block_fn is not None
-    native.block_steps = 64
-    native.run_mcmc(pos, 70)                                # a 64-step block and a 6-step block
-    python = EnsembleSampler(32, len(names), fit.lnprob_batch, vectorize=True, seed=11)
-    python.block_steps = 64
-    python.run_mcmc(pos, 70)
-    assert np.array_equal(native.chain, python.chain) and np.array_equal(native.lnprobability, python.lnprobability)
-    assert np.array_equal(native.acceptance_fraction, python.acceptance_fraction) and native.n_calls == python.n_calls
-    assert 0.05 < native.acceptance_fraction.mean() < 0.95 and np.all(np.isfinite(native.lnprobability))
+    for rng_mode in ("device", "host"):                     # numbers generated on the device (the default) / drawn by NumPy
+        fit.RNG = rng_mode
+        native = fit._make_sampler(32, seed=11)
+        assert isinstance(native, EnsembleSampler) and native.block_fn is not None and native.rng == rng_mode
+        native.block_steps = 64
+        native.run_mcmc(pos, 70)                            # a 64-step block and a 6-step block
+        python = EnsembleSampler(32, len(names), fit.lnprob_batch, vectorize=True, seed=11, rng=rng_mode)
+        python.block_steps = 64 if rng_mode == "host" else 9    # (host draws: the partition defines the stream; device: any)
+        python.run_mcmc(pos, 70)
+        assert np.array_equal(native.chain, python.chain) and np.array_equal(native.lnprobability, python.lnprobability)
+        assert np.array_equal(native.acceptance_fraction, python.acceptance_fraction) and native.n_calls == python.n_calls
+        assert 0.05 < native.acceptance_fraction.mean() < 0.95 and np.all(np.isfinite(native.lnprobability))
+    fit.RNG = "device"
     # through Runner.__call__ as a user would (restarts every n_out steps included)
     run = fit(n_walkers=32, n_steps=20, n_out=10, pos=pos, prefix=None)
     assert np.asarray(run.chain).shape == (32, 20, len(names))
