@@ -37,6 +37,9 @@ python tools/summarize_rocprof.py stats $O/prof_${TAG}_chain $P/${R}_chain_kerne
 python tools/chain_trace_summary.py $O/prof_${TAG}_chain/*/*_kernel_trace.csv > $P/${R}_chain_kernel_trace_summary.txt
 cp $O/chain_probe_$TAG.txt $P/${R}_chain_probe.txt
 { echo "# tools/fuzz_chain.py: resident vs host-driven stretch blocks, every bit compared; plain / every block cut into parts (MCD_CHAIN_PART_BYTES=1) / --force-rccl / --seeded (device-generated numbers: resident = host-driven = replay through mcd_chain_numbers) / --seeded in parts"; grep '^DONE' $O/fuzz_chain_$TAG.log; } > $P/${R}_fuzz_chain.txt
-python tools/summarize_rocprof.py pmc c3 $O/pmc_fetch_$TAG $O/pmc_write_$TAG $P/pmc_traffic.json loglike_kernel 64000000 > /dev/null
-python tools/summarize_rocprof.py sq $P/${R}_c3_sq_counters.json loglike_kernel 256000000 $O/sq_${TAG}_pass1 $O/sq_${TAG}_pass2 $O/sq_${TAG}_pass3 > /dev/null
+# (stage c of the sweep: the counter passes; a sweep without it keeps the committed counters -- the hot kernels decide them)
+if [ -d $O/pmc_fetch_$TAG ]; then
+    python tools/summarize_rocprof.py pmc c3 $O/pmc_fetch_$TAG $O/pmc_write_$TAG $P/pmc_traffic.json loglike_kernel 64000000 > /dev/null
+    python tools/summarize_rocprof.py sq $P/${R}_c3_sq_counters.json loglike_kernel 256000000 $O/sq_${TAG}_pass1 $O/sq_${TAG}_pass2 $O/sq_${TAG}_pass3 > /dev/null
+fi
 echo "profiles/${R}_* refreshed from sweep $TAG"
