@@ -176,6 +176,21 @@ def test_binned_block_equals_the_python_loop_of_the_binned_sampler():
     ref.run_mcmc(ref.chain[:, :, -1, :], 7, log_prob0=ref.lnprobability[:, :, -1])
     nat.run_mcmc(pos, 7, log_prob0=lnp)
     assert np.array_equal(nat.chain, ref.chain) and nat.iteration == 47
+    # the counter-based numbers of csrc/mcd_rng.h (rng="device"): the library's block loop fed block by block with the host
+    # build's numbers (what mcd_stretch_move_seeded does when it runs host-driven) == the NumPy loop fed by the library's own
+    # mcd_chain_numbers, whatever the block lengths
+    def seeded_block_fn(pos, lnp, seed, step0, n, chain, lnprob_chain, accepted):
+        order, zz, thr, pick = em.chain_numbers(seed, step0, n, B, W, P)
+        block_fn(pos, lnp, order, zz, thr, pick, chain, lnprob_chain, accepted)
+
+    dev_ref = BinnedSampler(B, W, P, lnprob, seed=31, rng="device")
+    dev_nat = BinnedSampler(B, W, P, lnprob, seed=31, rng="device", seeded_block_fn=seeded_block_fn)
+    dev_ref.device_block_steps, dev_nat.device_block_steps = 40, 13
+    dev_ref.run_mcmc(start, 40)
+    dev_nat.run_mcmc(start, 40)
+    assert np.array_equal(dev_nat.chain, dev_ref.chain) and np.array_equal(dev_nat.lnprobability, dev_ref.lnprobability)
+    assert np.array_equal(dev_nat.acceptance_fraction, dev_ref.acceptance_fraction)
+    assert not np.array_equal(dev_nat.chain, nat.chain[:, :, :40]) and 0.05 < dev_nat.acceptance_fraction.mean() < 0.95
 
 
 def test_device_rng_mode_python_loop_is_block_partition_invariant():
