@@ -1681,6 +1681,8 @@ int run_stretch(mcd_catalog* cat, const mcd_stretch_desc* d, int64_t n_steps, do
     const char* who = seed ? "mcd_stretch_move_seeded" : "mcd_stretch_move";
     if (!cat || !d || !pos || !lnp) return fail(MCD_ERR_INVALID, std::string(who) + ": null argument");
     if (!seed && (!order || !zz || !thr || !pick)) return fail(MCD_ERR_INVALID, std::string(who) + ": null argument");
+    if (seed && d->n_walkers > mcd::kSeededMaxWalkers)
+        return fail(MCD_ERR_INVALID, std::string(who) + ": the generator's ordering keys hold the walker index in 20 bits (n_walkers <= 1048576)");
     const int64_t B = d->n_bins > 1 ? d->n_bins : 1;
     if (B != cat->n_psets)
         return fail(MCD_ERR_INVALID, std::string(who) + ": desc->n_bins must equal the catalogue's number of parameter sets (radial bins)");
@@ -1760,6 +1762,7 @@ int mcd_chain_numbers(uint64_t seed, int64_t step0, int64_t n_steps, int64_t n_b
     try {
     if (!order || !zz || !thr || !pick || n_steps < 0 || step0 < 0 || n_walkers <= 0 || (n_walkers & 1) || n_dim <= 0)
         return fail(MCD_ERR_INVALID, "mcd_chain_numbers: bad arguments");
+    if (n_walkers > mcd::kSeededMaxWalkers) return fail(MCD_ERR_INVALID, "mcd_chain_numbers: n_walkers <= 1048576");
     const int64_t B = n_bins > 1 ? n_bins : 1, W = n_walkers, half = W / 2;
     std::vector<uint64_t> sorter;
     for (int64_t i = 0; i < n_steps; ++i)

@@ -107,6 +107,14 @@ def test_chain_numbers_have_the_stretch_moves_distributions():
     assert len(np.unique(zz)) == zz.size
 
 
+def test_walker_limit_of_the_ordering_keys():
+    from mcmc_dynamics_amd import _native as native
+    with pytest.raises(native.NativeError, match="n_walkers"):
+        native.chain_numbers(1, 0, 1, 1, (1 << 20) + 2, 3)
+    with pytest.raises(native.NativeError):
+        native.chain_numbers(1, 0, 1, 1, 7, 3)                 # odd
+
+
 def test_ordering_keys_rank_like_a_stable_argsort():
     keys = eh.chain_keys(5, 9, 2, 50)
     order = eh.chain_numbers(5, 9, 1, 3, 50, 3)[0][0, 2]
