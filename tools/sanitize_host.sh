@@ -9,7 +9,7 @@ cp tests/emul/libmcd_emul.so /tmp/libmcd_emul.so.plain 2>/dev/null || true
 g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer \
     -I mcmc_dynamics_amd/csrc tests/emul/mcd_emul.cpp -o tests/emul/libmcd_emul.so
 LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 \
-    python -m pytest tests/test_stretch_block_cpu.py tests/test_chunk_plan_cpu.py tests/test_guard_random_cpu.py tests/test_kernel_math_cpu.py -x -q
+    python -m pytest tests/test_stretch_block_cpu.py tests/test_chunk_plan_cpu.py tests/test_guard_random_cpu.py tests/test_kernel_math_cpu.py tests/test_chain_rng_cpu.py -x -q
 rc=$?
 rm -f tests/emul/libmcd_emul.so                       # the next test run rebuilds the plain library
 [ -f /tmp/libmcd_emul.so.plain ] && cp /tmp/libmcd_emul.so.plain tests/emul/libmcd_emul.so && touch tests/emul/libmcd_emul.so
