@@ -118,6 +118,50 @@ def test_c5_exact_shape_f64(native, ctx, c5):
     flat.close()
 
 
+def test_c5_exact_shape_seeded_chain(native, ctx, c5):
+    """C5 at its full size through the sampler's hot path: 55 ensembles of 512 walkers in lockstep, the move's random
+    numbers generated on the device (`mcd_stretch_move_seeded`).  Size-independent properties: the resident block equals the
+    host-driven block of the same seed bit for bit; every bin's chain equals the chain of a stand-alone catalogue of that
+    bin's stars run with the numbers `mcd_chain_numbers` gives for that bin (the bins are independent ensembles)."""
+    cols, offs, pos, centre = c5
+    B, W, P = len(offs) - 1, 512, 4
+    binned = native.Catalog(ctx, cols["ra"], cols["dec"], cols["v"], cols["verr"], model=native.MODEL_CONST, centre=centre,
+                            bin_offsets=offs)
+    rng = np.random.default_rng(55)
+    start = np.ascontiguousarray(np.broadcast_to(pos, (B, W, P)) * (1.0 + 0.01 * rng.normal(size=(B, W, P))))
+    start[..., 1] = np.abs(start[..., 1])
+    lnp0 = np.ascontiguousarray(binned.loglike(start))
+    plan = {"col_source": np.arange(P, dtype=np.int32), "col_const": np.zeros(P), "col_factor": np.ones(P),
+            "lo": np.array([-np.inf, 0.0, -np.inf, -np.inf]), "hi": np.full(P, np.inf), "fixed_ok": True}
+    seed, step0, n = 2026, 40, 6
+    runs = {}
+    for mode in (1, 0):
+        binned.set_option("device_chain", mode)
+        p, l = start.copy(), lnp0.copy()
+        chain, lnpc, acc = np.empty((n, B, W, P)), np.empty((n, B, W)), np.zeros((B, W), dtype=np.int64)
+        binned.stretch_move_seeded(plan, p, l, seed, step0, n, chain, lnpc, acc)
+        runs[mode] = (p, l, chain, lnpc, acc)
+    info = binned.stretch_info()
+    assert info["device_blocks"] == 1 and info["host_blocks"] == 1 and info["discarded_blocks"] == 0, info
+    assert all(np.array_equal(a, b) for a, b in zip(runs[1], runs[0]))
+    acc = runs[1][4]
+    assert np.all(np.isfinite(runs[1][3])) and np.all(acc.sum(axis=1) > 0) and acc.sum() < n * B * W
+    order, zz, thr, pick = native.chain_numbers(seed, step0, n, B, W, P)
+    for b in (0, B // 2, B - 1):
+        sl = slice(offs[b], offs[b + 1])
+        one = native.Catalog(ctx, cols["ra"][sl], cols["dec"][sl], cols["v"][sl], cols["verr"][sl], model=native.MODEL_CONST,
+                             centre=centre)
+        p, l = start[b].copy(), np.ascontiguousarray(one.loglike(start[b]))
+        chain1, lnpc1 = np.empty((n, W, P)), np.empty((n, W))
+        one.stretch_move(plan, p, l, np.ascontiguousarray(order[:, b]), np.ascontiguousarray(zz[:, :, b]),
+                         np.ascontiguousarray(thr[:, :, b]), np.ascontiguousarray(pick[:, :, b]), chain1, lnpc1)
+        # (a stand-alone catalogue has its own chunk table: the sums agree to rounding, so accept decisions may differ where
+        # a threshold is met within 1e-12 -- none does at this size; positions are then the same bits)
+        assert rel_err(lnpc1, runs[1][3][:, b]) < RTOL and np.array_equal(chain1, runs[1][2][:, b]), b
+        one.close()
+    binned.close()
+
+
 def test_c5_exact_shape_precision_sweep(native, ctx, c5):
     """float32 vs float64 at the full C5 shape: f32 terms + f64 accumulation <= 1e-6, pure f32 <= 2e-5 relative per
     (bin, walker) output (the tolerances of test_precision_sweep_c5; SURVEY appendix: 9.5e-9 / 1.8e-7 at 1e5 stars)."""
