@@ -56,8 +56,10 @@ class BinnedSampler(object):
         self._random = np.random.RandomState(seed)
         # rng="device": the 64-bit name of the chain (no seed: from NumPy's global generator, which the reference seeds at
         # analysis/runner.py:59 -- `np.random.seed` before the run makes it reproducible, as with emcee)
-        self.seed64 = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else \
-            (int(np.random.randint(0, 2 ** 32)) << 32) | int(np.random.randint(0, 2 ** 32))
+        self.seed64 = None
+        if rng == "device":                       # (only then: drawing a seed moves NumPy's global generator)
+            self.seed64 = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else \
+                (int(np.random.randint(0, 2 ** 32)) << 32) | int(np.random.randint(0, 2 ** 32))
         self.device_block_steps = 256             # rng="device": steps per library call (NOT part of the stream's definition)
         # the steps of a block are drawn by N_STREAMS generators seeded from the master (see run_mcmc: draw)
         self._streams = [np.random.RandomState(int(s)) for s in self._random.randint(0, 2 ** 31 - 1, size=self.N_STREAMS)]

@@ -48,8 +48,10 @@ class EnsembleSampler(object):
             raise ValueError("rng='device' implements the stretch move with a = 2 (emcee's default)")
         self.rng = rng
         self.seeded_block_fn = seeded_block_fn
-        self.seed64 = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else \
-            (int(np.random.randint(0, 2 ** 32)) << 32) | int(np.random.randint(0, 2 ** 32))
+        self.seed64 = None
+        if rng == "device":                       # (only then: drawing a seed moves NumPy's global generator)
+            self.seed64 = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else \
+                (int(np.random.randint(0, 2 ** 32)) << 32) | int(np.random.randint(0, 2 ** 32))
         if nwalkers < 2 * ndim:
             raise ValueError("The number of walkers must be at least twice the dimension.")   # as emcee
         if nwalkers % 2:
