@@ -305,6 +305,11 @@ class BinnedConstantFit(ConstantFit):
         if pos is None:
             pos = np.stack([self.get_initials(n_walkers) for _ in range(self.n_bins)])
         pos = np.asarray(pos, dtype=np.float64)
+        # several ranks (stars sharded): rank 0's start positions and ONE seed go to every rank, as in Runner.__call__
+        group = self._rank_group()
+        if group is not None:
+            pos = group.bcast_array(pos, src=0)
+            seed = int(group.bcast_json(int(seed) if seed is not None else int(np.random.SeedSequence().entropy % (2 ** 63)), src=0))
         lp = self.parameters.lnprior_batch(self.parameters.resolve_batch(pos.reshape(-1, pos.shape[-1])))
         if not np.all(np.isfinite(lp)):
             raise ValueError("Invalid initial guesses for {0} walker(s).".format(int(np.sum(~np.isfinite(lp)))))
