@@ -332,10 +332,10 @@ int mcd_last_prefetch(const mcd_catalog* cat);
 int mcd_last_fast_level(const mcd_catalog* cat);
 
 /* float32 accuracy domain (MCD_F32, MCD_F32_ACC64).  The float32 kernels round every record field and walker constant to
- * 24 bits first; they stay within 1e-6 (MCD_F32_ACC64) / 2e-5 (MCD_F32) of the float64 kernels -- fixed centre; 1e-5 /
+ * 24 bits first; they stay within 1e-6 (MCD_F32_ACC64) / 2e-5 (MCD_F32) of the float64 kernels -- fixed centre; 2e-5 /
  * 1e-4 with a free centre -- on the scale max(|lnL|, N, 32) only while
  *     kappa_v = (max|v| + |v_sys| + |v_maxx| + |v_maxy|) / sqrt(min(verr^2) + min(sigma^2))      <= 96
- *     kappa_theta = (|v_maxx| + |v_maxy|) / sqrt(min(verr^2) + min(sigma^2)) * 2^-23 / sep_harm   <= 4e-5   (free centre;
+ *     kappa_theta = (|v_maxx| + |v_maxy|) / sqrt(min(verr^2) + min(sigma^2)) * 2^-23 / sep_harm   <= 2e-5   (free centre;
  *                   sep_harm: harmonic mean angular separation [rad] of the stars from the catalogue's centroid)
  * and variances, residuals and mixture values lie in the float32 ranges (norm within 2^-15 .. 2^15, |v - v_los| <= 2^15,
  * lnL_bg within -80 .. 60, pmember <= 1 - 2^-20, density and f_back within 2^-20 .. 2^20); derivation in

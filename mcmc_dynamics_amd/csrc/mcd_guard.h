@@ -315,11 +315,13 @@ MCD_HD int level_verdict(const StatsScalars& st, int model, bool f32, int64_t n_
 //     position-angle error 2^-23 / separation, which the rotation term amplifies by v_rot / sqrt n.  Summed over the
 //     catalogue:  kappa_theta = (max(|v_maxx| + |v_maxy|) / sqrt(n_min)) 2^-23 / sep_harm, sep_harm the harmonic mean
 //     separation [rad] of the stars from the catalogue's centroid (CatalogStats).  Errors reach 8.5e-4 for compact
-//     catalogues with strong rotation and scale like 0.25 kappa_theta at worst: kappa_theta <= 4e-5 keeps them below 1e-5.
+//     catalogues with strong rotation; they are 0.002 kappa_theta in the median, 0.12 at the 99.9th percentile and 0.51 at
+//     worst over 350 000 cases (one star close to the centroid with a residual of many sigma; 12-star catalogue of the long
+//     campaign, profiles/r03_long_campaign.txt): kappa_theta <= 2e-5 keeps them below 2e-5 with a factor two to spare.
 // Stated tolerances inside the domain: fixed centre 1e-6 (MCD_F32_ACC64) / 2e-5 (MCD_F32: the float32 sums of 1e6 terms
-// add to the per-term error, tests/test_gpu_baseline_shapes.py); free centre 1e-5 / 1e-4.
+// add to the per-term error, tests/test_gpu_baseline_shapes.py); free centre 2e-5 / 1e-4.
 constexpr double kF32KappaV = 96.0;
-constexpr double kF32KappaTheta = 4.0e-5;
+constexpr double kF32KappaTheta = 2.0e-5;
 
 struct F32Domain {
     bool inside = false;
@@ -357,7 +359,7 @@ inline F32Domain f32_domain(const CatalogStats& st, int model, bool free_centre,
     out.kappa_theta = free_centre ? (st.sep_harm > 0.0 && n_min > 0.0 ? rot / std::sqrt(n_min) * 0x1p-23 / st.sep_harm : kInfinity) : 0.0;
     if (!ranges_ok) out.reason = "variances, residuals or mixture values outside the float32 ranges (norm within 2^-15 .. 2^15, |v - v_los| <= 2^15, lnL_bg within -80 .. 60, pmember <= 1 - 2^-20, density and f_back within 2^-20 .. 2^20)";
     else if (!(out.kappa_v <= kF32KappaV)) out.reason = "(max|v| + |v_sys| + |v_maxx| + |v_maxy|) / sqrt(min(verr^2) + sigma^2) exceeds 96: the float32 rounding of the velocities is amplified beyond the stated tolerance";
-    else if (free_centre && !(out.kappa_theta <= kF32KappaTheta)) out.reason = "free centre: rotation amplitude over dispersion times 2^-23 / (harmonic mean separation of the stars) exceeds 4e-5: the float32 tangent-plane offsets are too coarse for this catalogue";
+    else if (free_centre && !(out.kappa_theta <= kF32KappaTheta)) out.reason = "free centre: rotation amplitude over dispersion times 2^-23 / (harmonic mean separation of the stars) exceeds 2e-5: the float32 tangent-plane offsets are too coarse for this catalogue";
     else out.inside = true;
     return out;
 }

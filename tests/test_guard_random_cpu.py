@@ -135,7 +135,7 @@ def test_float32_accuracy_domain():
     free = np.column_stack([pos, np.full(64, centre[0]), np.full(64, centre[1])])
     inside, _, kt, sep, why = emul.f32_domain(c, free, 0, None)
     assert sep > 0 and kt > 0
-    assert inside == (kt <= 4e-5) and (inside or "tangent-plane" in why)
+    assert inside == (kt <= 2e-5) and (inside or "tangent-plane" in why)
     rng = np.random.default_rng(2)
     wide = dict(c)
     sepd = np.abs(rng.normal(0, 0.5, 20000)) + 0.05                                  # degrees

@@ -11,7 +11,7 @@ mcd_last_f32_domain() tells whether the call was inside the domain).  Error scal
 |lnL32 - lnL64| / max(|lnL64|, N, 32).  Reported: worst error inside / outside the domain per precision and centre mode; that
 every call outside the domain is refused (MCD_ERR_INVALID) when the option is on; the cases beyond the stated tolerances
 inside the domain (exit status 1 if there is one):
-    fixed centre  f32acc64 1e-6    f32 2e-5        free centre  f32acc64 1e-5    f32 1e-4
+    fixed centre  f32acc64 1e-6    f32 2e-5        free centre  f32acc64 2e-5    f32 1e-4
 """
 import argparse
 import os
@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mcmc_dynamics_amd import _native as native  # noqa: E402
 from test_guard_random_cpu import CENTRE, random_case  # noqa: E402
 
-TOL = {(False, "f32acc64"): 1e-6, (False, "f32"): 2e-5, (True, "f32acc64"): 1e-5, (True, "f32"): 1e-4}
+TOL = {(False, "f32acc64"): 1e-6, (False, "f32"): 2e-5, (True, "f32acc64"): 2e-5, (True, "f32"): 1e-4}
 
 
 def realistic_case(rng, model, n, w):
