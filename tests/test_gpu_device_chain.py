@@ -546,3 +546,41 @@ def test_seeded_binned_blocks_and_the_sampler_modes(native, parts, monkeypatch):
     assert s.rng == "device" and s.chain.shape == (B, W, 6, P)
     s.close()
     bf.close()
+
+
+def test_seeded_block_edge_cases(native, ctx):
+    """No steps, no outputs, only one of the outputs, accepted counts that continue, bad arguments."""
+    rng = np.random.default_rng(9900)
+    cat, sv = _catalogue(native, ctx, rng, 4001, 0, False)
+    w = 24
+    pos = _walkers(rng, w, 0, sv, False)
+    lnp = cat.loglike(pos)
+    plan = identity_plan(4, lo=[-np.inf, 0.0, -np.inf, -np.inf])
+    full = run_seeded(cat, plan, pos, lnp, 5, 0, 9, device=1)
+    # zero steps: nothing changes
+    p, l = pos.copy(), lnp.copy()
+    cat.stretch_move_seeded(plan, p, l, 5, 0, 0)
+    assert np.array_equal(p, pos) and np.array_equal(l, lnp)
+    for mode in (1, 0):
+        cat.set_option("device_chain", mode)
+        # no outputs at all; only the log-probabilities; accepted counts continue from what the caller passes
+        p, l = pos.copy(), lnp.copy()
+        cat.stretch_move_seeded(plan, p, l, 5, 0, 9)
+        assert np.array_equal(p, full[0]) and np.array_equal(l, full[1])
+        p, l, lnpc = pos.copy(), lnp.copy(), np.empty((9, w))
+        cat.stretch_move_seeded(plan, p, l, 5, 0, 9, None, lnpc)
+        assert np.array_equal(lnpc, full[3])
+        p, l, acc = pos.copy(), lnp.copy(), np.full(w, 100, dtype=np.int64)
+        cat.stretch_move_seeded(plan, p, l, 5, 0, 9, None, None, acc)
+        assert np.array_equal(acc, full[4] + 100)
+    # a seed is 64 bits; negative Python integers wrap
+    a = run_seeded(cat, plan, pos, lnp, -1, 0, 3, device=1)
+    b = run_seeded(cat, plan, pos, lnp, 2 ** 64 - 1, 0, 3, device=1)
+    assert same(a, b) and not np.array_equal(a[2], full[2][:3])
+    with pytest.raises(ValueError):
+        cat.stretch_move_seeded(plan, pos.copy(), lnp.copy(), 5, -1, 3)
+    with pytest.raises(ValueError):
+        cat.stretch_move_seeded(plan, pos.copy(), lnp[:-1].copy(), 5, 0, 3)
+    with pytest.raises(native.NativeError):
+        cat.stretch_move_seeded(plan, pos[:-1].copy(), lnp[:-1].copy(), 5, 0, 3)      # odd number of walkers
+    cat.close()
