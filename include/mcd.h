@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MCD_ABI_VERSION 1
+#define MCD_ABI_VERSION 1          /* bumped when an existing signature or struct layout changes; additions keep it */
 #define MCD_UNIQUE_ID_BYTES 128
 
 typedef struct mcd_ctx mcd_ctx;          /* devices + streams (+ RCCL communicator when > 1 rank) */

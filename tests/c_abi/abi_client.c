@@ -28,7 +28,10 @@ int main(int argc, char** argv) {
         (any_fn)mcd_last_error, (any_fn)mcd_abi_version, (any_fn)mcd_last_kernel_ms,
         (any_fn)mcd_last_device_ms, (any_fn)mcd_set_option, (any_fn)mcd_timing_collect,
         (any_fn)mcd_rerun_count, (any_fn)mcd_last_fast_level, (any_fn)mcd_last_launch_info,
-        (any_fn)mcd_ctx_comm_info, (any_fn)mcd_stretch_move, (any_fn)mcd_stretch_info, (any_fn)mcd_last_prefetch};
+        (any_fn)mcd_ctx_comm_info, (any_fn)mcd_stretch_move, (any_fn)mcd_stretch_info, (any_fn)mcd_last_prefetch,
+        /* round 3 (additions: the ABI version stays) */
+        (any_fn)mcd_ctx_set_option, (any_fn)mcd_ctx_abort, (any_fn)mcd_ctx_failed, (any_fn)mcd_last_f32_domain,
+        (any_fn)mcd_stretch_move_seeded, (any_fn)mcd_chain_numbers};
     size_t i;
     double out[3] = {0.0, 0.0, 0.0};
     for (i = 0; i < sizeof table / sizeof table[0]; ++i) CHECK(table[i] != NULL);
@@ -44,6 +47,10 @@ int main(int argc, char** argv) {
     CHECK(mcd_ctx_comm_info(NULL, NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_stretch_move(NULL, NULL, 1, out, out, NULL, out, out, NULL, NULL, NULL, NULL) != MCD_OK);
     CHECK(mcd_stretch_info(NULL, NULL, NULL, NULL, NULL) != MCD_OK);
+    CHECK(mcd_stretch_move_seeded(NULL, NULL, 1, out, out, 1, 0, NULL, NULL, NULL) != MCD_OK);
+    CHECK(mcd_chain_numbers(1, 0, 1, 1, 3, 2, NULL, NULL, NULL, NULL) != MCD_OK);      /* odd walker count, null outputs */
+    CHECK(mcd_ctx_set_option(NULL, "collective_timeout_ms", 1) != MCD_OK);
+    CHECK(mcd_ctx_failed(NULL) == 0);
     CHECK(mcd_catalog_destroy(NULL) == MCD_OK);
     CHECK(mcd_ctx_destroy(NULL) == MCD_OK);
     printf("abi %d: %d entry points link from C\n", mcd_abi_version(), (int)(sizeof table / sizeof table[0]));
