@@ -736,11 +736,7 @@ struct LogProductF {                 // sum of logs as log of a product, mantiss
     }
     MCD_HD double value() {
         rescale();
-#if defined(__HIP_DEVICE_COMPILE__)
-        return fma_((double)e, kLn2, log((double)p));
-#else
-        return fma_((double)e, kLn2, std::log((double)p));
-#endif
+        return fma_((double)e, kLn2, log_unit((double)p));
     }
 };
 // BG_FIXED / BG_FIXED_DENSITY:  y = w0 + g exp(nbp - 1/2 d^2 g^2),  w0 = 1 - p (record) or f_back (walker)
