@@ -14,6 +14,7 @@ run env MCD_CHAIN_PART_BYTES=1 python tools/fuzz_chain.py --trials 2000 --second
 run python tools/fuzz_chain.py --trials 2000 --seconds 100 --seed $((107 + S)) --force-rccl
 run python tools/fuzz_chain.py --trials 2000 --seconds 150 --seed $((109 + S)) --seeded
 run env MCD_CHAIN_PART_BYTES=1 python tools/fuzz_chain.py --trials 2000 --seconds 100 --seed $((113 + S)) --seeded
+run python tools/fuzz_chain.py --trials 2000 --seconds 60 --seed $((301 + S)) --seeded --force-rccl
 run python tools/fuzz_gpu.py --trials 100000 --seconds 150 --schedule --max-walkers 640 --max-stars 5000 --seed $((127 + S))
 run python tools/fuzz_f32.py --seconds 120 --seed $((131 + S))
 grep -E '^###|^DONE' $L
